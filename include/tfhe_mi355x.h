@@ -1,0 +1,169 @@
+/*
+ * tfhe_mi355x.h — C ABI of the MI355X-native TFHE gate-bootstrapping engine (libtfhe_mi355x.so).
+ *
+ * The reference (nucypher/TFHE.jl) has no FFI for this path: it is plain Julia.  This header is the
+ * drop-in boundary a `ccall` shim binds instead of the Julia functions cited per entry point
+ * (paths relative to the reference checkout).  Plain pointers and sizes only; no C++ types, no
+ * exceptions cross the boundary.  Every function returns 0 on success or a TFHE_ERR_* code;
+ * tfhe_last_error() gives the message for the last failure on that context.
+ *
+ * Data formats (all Torus32 = int32_t, wrapping two's-complement arithmetic):
+ *   LWE sample      : int32[n+1]          = a[0..n-1], b            (lwe.jl:21-29)
+ *   extracted sample: int32[k*N+1]        = a[0..kN-1], b           (tlwe.jl:55-59)
+ *   bootstrapping key, canonical Int32 form:
+ *       int32 [n][l][k+1][k+1][N]  = key[i].samples[p, j].a[c]      (bootstrap.jl:1-16, tgsw.jl:25-42)
+ *       i.e. the inverse_transform of the spectra the reference stores (bootstrap.jl:12-14)
+ *   bootstrapping key, the reference's stored form:
+ *       complex128 [n][l][k+1][k+1][N/2] (re,im interleaved)        (polynomials.jl:12-14,106-112)
+ *   keyswitch key   : int32 [kN][t][base-1][n+1] = key[h, j, i]     (keyswitch.jl:7-42; h fastest in Julia)
+ *   MK sample       : int32[P*n+1]        = a[:,0], a[:,1], ..., b  (mk_internals.jl:6-18)
+ *   MK bootstrap key: int32 [P][n][2*l*P + 2*l][N], per (party i, bit j) the polys
+ *       x[l][P], y[l][P], c0[l], c1[l]                              (mk_internals.jl:243-271,442-461)
+ *   MK keyswitch key: P single-key keyswitch keys back to back      (mk_api.jl:83-101)
+ *
+ * Ownership: the caller owns every host buffer for the duration of the call only; the library
+ * copies keys to the device at load time and owns all device memory.  A context is bound to one
+ * device; calls on one context must not overlap (one caller at a time), distinct contexts are
+ * independent (one per GPU, one process per GPU in the benchmark).
+ */
+#ifndef TFHE_MI355X_H
+#define TFHE_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHE_MI355X_ABI_VERSION 1
+
+/* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
+typedef struct tfhe_params {
+    int32_t n;            /* lwe_size                                  api.jl:6   */
+    int32_t N;            /* tlwe_polynomial_degree (power of two)     api.jl:9   */
+    int32_t k;            /* tlwe_mask_size                            api.jl:10  */
+    int32_t bs_l;         /* bs_decomp_length                          api.jl:12  */
+    int32_t bs_log2_base; /* bs_log2_base                              api.jl:13  */
+    int32_t ks_t;         /* ks_decomp_length                          api.jl:16  */
+    int32_t ks_log2_base; /* ks_log2_base                              api.jl:17  */
+    int32_t parties;      /* max_parties (1 = single key)              api.jl:20  */
+} tfhe_params;
+
+typedef struct tfhe_ctx tfhe_ctx;
+
+/* error codes */
+enum {
+    TFHE_OK = 0,
+    TFHE_ERR_INVALID_ARG = 1,  /* NULL pointer, bad size, bad opcode                       */
+    TFHE_ERR_UNSUPPORTED = 2,  /* parameter set outside what the kernels are built for      */
+    TFHE_ERR_NO_KEY = 3,       /* a key needed by the call has not been loaded              */
+    TFHE_ERR_DEVICE = 4,       /* HIP runtime error (no device, allocation, launch, ...)    */
+    TFHE_ERR_STATE = 5
+};
+
+/* Gate opcodes for tfhe_gates_batch — one per exported gate_* function (TFHE.jl:34-46). */
+enum {
+    TFHE_GATE_NAND = 0,    /* gate_nand    gates.jl:15-18   */
+    TFHE_GATE_OR = 1,      /* gate_or      gates.jl:27-30   */
+    TFHE_GATE_AND = 2,     /* gate_and     gates.jl:39-42   */
+    TFHE_GATE_XOR = 3,     /* gate_xor     gates.jl:51-54   */
+    TFHE_GATE_XNOR = 4,    /* gate_xnor    gates.jl:63-66   */
+    TFHE_GATE_NOT = 5,     /* gate_not     gates.jl:76-79   (no bootstrap) */
+    TFHE_GATE_NOR = 6,     /* gate_nor     gates.jl:102-105 */
+    TFHE_GATE_ANDNY = 7,   /* gate_andny   gates.jl:114-117 */
+    TFHE_GATE_ANDYN = 8,   /* gate_andyn   gates.jl:126-129 */
+    TFHE_GATE_ORNY = 9,    /* gate_orny    gates.jl:138-141 */
+    TFHE_GATE_ORYN = 10,   /* gate_oryn    gates.jl:150-153 */
+    TFHE_GATE_MUX = 11,    /* gate_mux     gates.jl:163-177 (2 blind rotations + 1 keyswitch) */
+    TFHE_GATE_CONST0 = 12, /* gate_constant(ck, false)  gates.jl:91-93 */
+    TFHE_GATE_CONST1 = 13, /* gate_constant(ck, true)   gates.jl:91-93 */
+    TFHE_GATE_COPY = 14,   /* identity (circuit plumbing; no reference counterpart needed) */
+    TFHE_GATE__COUNT = 15
+};
+
+/* ---- library / context ------------------------------------------------------------------- */
+
+/* ABI version of the loaded library (== TFHE_MI355X_ABI_VERSION it was built with). */
+int32_t tfhe_abi_version(void);
+
+/* Number of HIP devices visible to this process (<0: runtime error). */
+int32_t tfhe_device_count(void);
+
+/* Replaces the implicit construction of TGswParams / KeyswitchParameters / LweParams from
+ * SchemeParameters (api.jl:72-82, tgsw.jl:8-21) and validates what the reference does not
+ * (api.jl:4-21 has no checks): N power of two, bs_l*bs_log2_base <= 32, ks_t*ks_log2_base <= 31. */
+int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx **out_ctx);
+void tfhe_ctx_destroy(tfhe_ctx *ctx);
+
+/* Message of the last error on ctx (ctx == NULL: last error of a failed tfhe_ctx_create). */
+const char *tfhe_last_error(const tfhe_ctx *ctx);
+
+/* Copies the parameters the context was created with. */
+int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
+
+/* ---- keys (replace CloudKey's object graphs, api.jl:111-127) -------------------------------- */
+
+/* BootstrapKey (bootstrap.jl:1-16) from the canonical Int32 form [n][l][k+1][k+1][N].
+ * The engine forward-transforms it on the device into its own spectrum-domain layout
+ * (the analogue of `forward_transform.(bk)`, bootstrap.jl:12). */
+int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk);
+
+/* BootstrapKey from the reference's stored spectra, complex128 [n][l][k+1][k+1][N/2] as produced by
+ * polynomials.jl:106-112; the engine applies the reference's inverse_transform (polynomials.jl:119-132,
+ * exact: values are integers) on the device and proceeds as above. */
+int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra);
+
+/* KeyswitchKey (keyswitch.jl:7-42), Int32 [kN][t][base-1][n+1]. */
+int32_t tfhe_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* B independent gates: out[g] = gate_<opcode[g]>(ck, in0[g], in1[g], in2[g])   (gates.jl:15-177).
+ * in0/in1/in2/out: host int32 [B][n+1].  in1 may be NULL if no opcode reads a 2nd operand,
+ * in2 may be NULL if no opcode is MUX. */
+int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
+                         const int32_t *in2, int32_t *out, int64_t B);
+
+/* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`
+ * (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host except
+ * for the upload of the B opcode bytes; results are ordered on `stream`. */
+int32_t tfhe_gates_batch_dev(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *d_in0,
+                             const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, int64_t B,
+                             void *stream);
+
+/* bootstrap(bk, ks, mu, x) (bootstrap.jl:92-95) if with_keyswitch != 0, else
+ * bootstrap_wo_keyswitch(bk, mu, x) (bootstrap.jl:69-82).
+ * in: host int32 [B][n+1]; out: host int32 [B][n+1] or [B][k*N+1]. */
+int32_t tfhe_bootstrap_batch(tfhe_ctx *ctx, int32_t mu, const int32_t *in, int32_t *out, int64_t B,
+                             int32_t with_keyswitch);
+
+/* keyswitch(ks, sample) (keyswitch.jl:45-80). in: host int32 [B][k*N+1]; out: host int32 [B][n+1]. */
+int32_t tfhe_keyswitch_batch(tfhe_ctx *ctx, const int32_t *in, int32_t *out, int64_t B);
+
+/* ---- multi-key (mk_gates.jl:7-12, mk_internals.jl:348-411,464-515) --------------------------- */
+
+/* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file). */
+int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk, int32_t parties);
+/* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]. */
+int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks, int32_t parties);
+/* out[g] = mk_gate_nand(ck, in0[g], in1[g]); all host int32 [B][P*n+1]. */
+int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *ctx, const int32_t *in0, const int32_t *in1, int32_t *out,
+                                int64_t B);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Timing of the most recent batch call on ctx, from HIP events recorded on the stream the kernels
+ * were launched on.  which: 0 = blind-rotate kernel(s), 1 = keyswitch kernel(s), 2 = whole batch
+ * (prologue .. last kernel, device side).  Blocks until those kernels have finished. */
+int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
+
+/* Number of blind rotations the most recent batch call executed (MUX counts 2). */
+int64_t tfhe_last_rotation_count(const tfhe_ctx *ctx);
+
+/* Selects a kernel variant by name for tuning / A-B benchmarking ("" or NULL = default). */
+int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_MI355X_H */

@@ -1,0 +1,76 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def have_gpu():
+    """True if the HIP library loads and sees a device (counting devices does not initialise one)."""
+    try:
+        import tfhe_jl_amd as t
+        return t._lib.load().tfhe_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def tfhe():
+    import tfhe_jl_amd
+    return tfhe_jl_amd
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+class KeySet:
+    """Key pair (package keygen, seed 123 as test/runtests.jl:27) + an oracle loaded with the same keys."""
+
+    def __init__(self, tfhe, orc, params, seed=123):
+        self.rng = np.random.default_rng(seed)
+        self.params = params
+        self.sk, self.ck = tfhe.make_key_pair(self.rng, params)
+        p = params
+        self.oracle = orc.Oracle(p.lwe_size, p.tlwe_polynomial_degree, p.tlwe_mask_size, p.bs_decomp_length,
+                                 p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base)
+        self.oracle.load_bootstrap_key(self.ck.bootstrap_key)
+        self.oracle.load_keyswitch_key(self.ck.keyswitch_key)
+
+
+@pytest.fixture(scope="session")
+def keys80(tfhe, orc):
+    return KeySet(tfhe, orc, tfhe.tfhe_parameters_80())
+
+
+@pytest.fixture(scope="session")
+def keys128(tfhe, orc):
+    return KeySet(tfhe, orc, tfhe.tfhe_parameters_128())
+
+
+@pytest.fixture(scope="session")
+def host_sim():
+    """tests/host_sim/sim_br.cpp compiled with g++: the kernel's lane code executed on the CPU."""
+    import ctypes as C
+    d = os.path.join(ROOT, "tests", "host_sim")
+    so = os.path.join(d, "libsim_br.so")
+    src = os.path.join(d, "sim_br.cpp")
+    hdr = os.path.join(ROOT, "tfhe.jl_amd", "csrc", "br_core.hpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.sim_blind_rotate.restype = C.c_double
+    lib.sim_freq_of.restype = C.c_int32
+    return lib

@@ -1,0 +1,151 @@
+"""GPU parity tests: the HIP path through the C ABI vs the oracle on identical keys and inputs.
+Bit-exact on every Int32 word.  Run with -m gpu on an MI355X."""
+import itertools
+
+import numpy as np
+import pytest
+
+from test_oracle import GATES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng80(tfhe, keys80):
+    return keys80.ck.engine(0)
+
+
+@pytest.fixture(scope="module")
+def eng128(tfhe, keys128):
+    return keys128.ck.engine(0)
+
+
+def test_native_library_is_the_one_loaded(tfhe, eng80):
+    import os
+    assert os.path.exists(tfhe.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libtfhe_mi355x.so" in maps
+
+
+@pytest.mark.parametrize("name,nargs,ref", GATES, ids=[g[0] for g in GATES])
+def test_gate_parity_and_truth_table_80(tfhe, orc, keys80, eng80, name, nargs, ref):
+    K = keys80
+    combos = list(itertools.product((False, True), repeat=nargs)) * 2
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(nargs)]
+    ops = np.full(len(combos), tfhe.OPCODES[name], np.uint8)
+    got = eng80.gates(ops, *ins)
+    want = K.oracle.gates(ops, *ins, nthreads=8)
+    assert np.array_equal(got, want)
+    assert list(tfhe.decrypt(K.sk, got)) == [bool(ref(*c)) for c in combos]
+
+
+def test_reference_api_mirror(tfhe, keys80, eng80):
+    """gate_*(ck, x, y) with the reference's names: scalar, vector, constant, not."""
+    K = keys80
+    t, f = tfhe.encrypt(K.rng, K.sk, True), tfhe.encrypt(K.rng, K.sk, False)
+    assert tfhe.decrypt(K.sk, tfhe.gate_nand(K.ck, t, t)) is False
+    assert tfhe.decrypt(K.sk, tfhe.gate_mux(K.ck, f, t, f)) is False
+    assert tfhe.decrypt(K.sk, tfhe.gate_not(K.ck, f)) is True
+    assert tfhe.decrypt(K.sk, tfhe.gate_constant(K.ck, True)) is True
+    xs = tfhe.encrypt(K.rng, K.sk, [True, False, True, False])
+    ys = tfhe.encrypt(K.rng, K.sk, [True, True, False, False])
+    assert list(tfhe.decrypt(K.sk, tfhe.gate_xor(K.ck, xs, ys))) == [False, True, True, False]
+
+
+def test_mixed_gate_stream_parity(tfhe, orc, keys80, eng80):
+    """BASELINE config 3 in miniature: i.i.d. opcodes over {NAND, AND, OR, XOR, MUX} + the trivial ones."""
+    K = keys80
+    rng = np.random.default_rng(789)
+    names = ["NAND", "AND", "OR", "XOR", "MUX", "NOT", "CONST1", "COPY", "XNOR", "ORYN"]
+    B = 96
+    ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+    got = eng80.gates(ops, *ins)
+    want = K.oracle.gates(ops, *ins, nthreads=8)
+    assert np.array_equal(got, want)
+    n_mux = int(np.sum(ops == tfhe.OPCODES["MUX"]))
+    n_triv = int(np.sum(np.isin(ops, [tfhe.OPCODES[x] for x in ("NOT", "CONST1", "COPY")])))
+    assert eng80.last_rotation_count() == B - n_triv + n_mux
+
+
+def test_bootstrap_and_keyswitch_entry_points(tfhe, orc, keys80, eng80):
+    K = keys80
+    rng = np.random.default_rng(42)
+    x = rng.integers(-2**31, 2**31, size=(16, 501), dtype=np.int64).astype(np.int32)   # arbitrary words
+    x[0, :] = 0
+    x[1, :7] = [2**31 - 1, -2**31, 2**20, 2**20 - 1, -2**20, -2**20 - 1, 1]
+    mu = 2**29
+    ext = eng80.bootstrap(mu, x, with_keyswitch=False)
+    assert np.array_equal(ext, K.oracle.bootstrap(mu, x, with_keyswitch=False, nthreads=8))
+    assert np.array_equal(eng80.keyswitch(ext), K.oracle.keyswitch(ext))
+    assert np.array_equal(eng80.bootstrap(mu, x, with_keyswitch=True), K.oracle.bootstrap(mu, x, nthreads=8))
+    # a different mu (bootstrap's argument, bootstrap.jl:92)
+    assert np.array_equal(eng80.bootstrap(-12345, x[:2]), K.oracle.bootstrap(-12345, x[:2]))
+    # keyswitch on arbitrary (non-bootstrapped) words, incl. all-zero digits
+    y = rng.integers(-2**31, 2**31, size=(8, 1025), dtype=np.int64).astype(np.int32)
+    y[0, :] = 0
+    y[1, :-1] = -2**15    # aibar = 0: every digit zero
+    assert np.array_equal(eng80.keyswitch(y), K.oracle.keyswitch(y))
+
+
+def test_gate_parity_128(tfhe, orc, keys128, eng128):
+    K = keys128
+    combos = list(itertools.product((False, True), repeat=3)) * 2
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    for name in ("NAND", "MUX", "XOR"):
+        ops = np.full(len(combos), tfhe.OPCODES[name], np.uint8)
+        got = eng128.gates(ops, *ins)
+        assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=8))
+    got = eng128.gates(np.full(len(combos), tfhe.OPCODES["NAND"], np.uint8), *ins)
+    assert list(tfhe.decrypt(K.sk, got)) == [not (c[0] and c[1]) for c in combos]
+
+
+def test_spectra_key_load_equals_int32_load(tfhe, orc, keys80, eng80):
+    """tfhe_load_bootstrap_key_c128 (the reference's stored form, bootstrap.jl:12-14) gives the same engine."""
+    K = keys80
+    e2 = tfhe.Engine(K.params, 0)
+    e2.load_bootstrap_key_spectra(K.oracle.bk_spectra())
+    e2.load_keyswitch_key(K.ck.keyswitch_key)
+    x = tfhe.encrypt(K.rng, K.sk, [True, False, True, False]).data
+    y = tfhe.encrypt(K.rng, K.sk, [True, True, False, False]).data
+    ops = np.full(4, tfhe.OPCODES["NAND"], np.uint8)
+    assert np.array_equal(e2.gates(ops, x, y), eng80.gates(ops, x, y))
+    e2.close()
+
+
+def test_edge_cases_and_errors(tfhe, keys80, eng80):
+    K = keys80
+    empty = np.zeros((0, 501), np.int32)
+    assert eng80.gates(np.zeros(0, np.uint8), empty, empty).shape == (0, 501)
+    x = tfhe.encrypt(K.rng, K.sk, [True]).data
+    with pytest.raises(tfhe.EngineError):
+        eng80.gates(np.array([99], np.uint8), x, x)          # bad opcode
+    with pytest.raises(tfhe.EngineError):
+        eng80.gates(np.array([tfhe.OPCODES["MUX"]], np.uint8), x, x, None)   # MUX needs a third operand
+    e = tfhe.Engine(K.params, 0)
+    with pytest.raises(tfhe.EngineError) as ei:
+        e.gates(np.array([0], np.uint8), x, x)               # keys not loaded
+    assert ei.value.code == 3
+    e.close()
+    with pytest.raises(tfhe.EngineError):
+        tfhe.Engine(K.params, 99)                            # no such device
+
+
+def test_full_batch_4096_properties(tfhe, orc, keys80, eng80):
+    """BASELINE config 2 size: every output decrypts to NAND; a sample of indices is bit-equal to the oracle;
+    the batch is deterministic and independent of batch position."""
+    K = keys80
+    rng = np.random.default_rng(456)
+    B = 4096
+    bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
+    ops = np.zeros(B, np.uint8)
+    got = eng80.gates(ops, x, y)
+    assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
+    idx = rng.choice(B, 64, replace=False)
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=8))
+    perm = rng.permutation(B)
+    got2 = eng80.gates(ops, x[perm], y[perm])
+    assert np.array_equal(got2, got[perm])
+    assert eng80.last_rotation_count() == B
+    assert eng80.last_timing_ms(0) > 0 and eng80.last_timing_ms(1) > 0

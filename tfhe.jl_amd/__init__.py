@@ -1,0 +1,22 @@
+"""tfhe.jl_amd — MI355X-native TFHE gate bootstrapping behind the reference's gate_*/key API.
+
+Exports mirror src/TFHE.jl:24-61 of nucypher/TFHE.jl.  The hot path (gate_* -> bootstrap ->
+keyswitch) runs in hand-written HIP kernels (csrc/, C ABI in include/tfhe_mi355x.h); key generation,
+encryption and decryption stay on the host, as in the reference.
+"""
+from .params import (SchemeParameters, tfhe_parameters_80, tfhe_parameters_128,
+                     mktfhe_parameters_2party, mktfhe_parameters_4party, mktfhe_parameters_8party)
+from .lwe import LweSample, LweSampleArray
+from .keys import SecretKey, CloudKey, make_key_pair, encrypt, decrypt
+from .gates import (gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not, gate_constant, gate_nor,
+                    gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux, gates_batch)
+from ._lib import Engine, EngineError, OPCODES, LIB_PATH
+
+__all__ = [
+    "make_key_pair", "LweSample", "LweSampleArray", "SecretKey", "CloudKey", "encrypt", "decrypt",
+    "tfhe_parameters_80", "tfhe_parameters_128", "SchemeParameters",
+    "gate_nand", "gate_or", "gate_and", "gate_xor", "gate_xnor", "gate_not", "gate_constant", "gate_nor",
+    "gate_andny", "gate_andyn", "gate_orny", "gate_oryn", "gate_mux", "gates_batch",
+    "mktfhe_parameters_2party", "mktfhe_parameters_4party", "mktfhe_parameters_8party",
+    "Engine", "EngineError", "OPCODES", "LIB_PATH",
+]

@@ -1,0 +1,202 @@
+"""ctypes binding of lib/libtfhe_mi355x.so (C ABI: include/tfhe_mi355x.h).
+
+There is no CPU fallback: if the HIP library is missing or no device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtfhe_mi355x.so")
+
+# symbols include/tfhe_mi355x.h declares (tests check that the .so exports every one of them)
+ABI_SYMBOLS = [
+    "tfhe_abi_version", "tfhe_device_count", "tfhe_ctx_create", "tfhe_ctx_destroy", "tfhe_last_error",
+    "tfhe_ctx_params", "tfhe_load_bootstrap_key_i32", "tfhe_load_bootstrap_key_c128",
+    "tfhe_load_keyswitch_key", "tfhe_gates_batch", "tfhe_gates_batch_dev", "tfhe_bootstrap_batch",
+    "tfhe_keyswitch_batch", "tfhe_mk_load_bootstrap_key_i32", "tfhe_mk_load_keyswitch_key",
+    "tfhe_mk_gate_nand_batch", "tfhe_last_timing_ms", "tfhe_last_rotation_count", "tfhe_set_option",
+]
+
+OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
+               MUX=11, CONST0=12, CONST1=13, COPY=14)
+
+
+class TfheParams(C.Structure):
+    _fields_ = [(f, C.c_int32) for f in
+                ("n", "N", "k", "bs_l", "bs_log2_base", "ks_t", "ks_log2_base", "parties")]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"tfhe_mi355x error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tfhe.jl_amd/csrc` (hipcc, gfx950). The engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.tfhe_abi_version.restype = i32
+    lib.tfhe_device_count.restype = i32
+    lib.tfhe_ctx_create.argtypes = [C.POINTER(TfheParams), i32, C.POINTER(vp)]
+    lib.tfhe_ctx_destroy.argtypes = [vp]
+    lib.tfhe_ctx_destroy.restype = None
+    lib.tfhe_last_error.argtypes = [vp]
+    lib.tfhe_last_error.restype = C.c_char_p
+    lib.tfhe_ctx_params.argtypes = [vp, C.POINTER(TfheParams)]
+    lib.tfhe_load_bootstrap_key_i32.argtypes = [vp, vp]
+    lib.tfhe_load_bootstrap_key_c128.argtypes = [vp, vp]
+    lib.tfhe_load_keyswitch_key.argtypes = [vp, vp]
+    lib.tfhe_gates_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+    lib.tfhe_gates_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.tfhe_bootstrap_batch.argtypes = [vp, i32, vp, vp, i64, i32]
+    lib.tfhe_keyswitch_batch.argtypes = [vp, vp, vp, i64]
+    lib.tfhe_mk_load_bootstrap_key_i32.argtypes = [vp, vp, i32]
+    lib.tfhe_mk_load_keyswitch_key.argtypes = [vp, vp, i32]
+    lib.tfhe_mk_gate_nand_batch.argtypes = [vp, vp, vp, vp, i64]
+    lib.tfhe_last_timing_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    lib.tfhe_last_rotation_count.argtypes = [vp]
+    lib.tfhe_last_rotation_count.restype = i64
+    lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Engine:
+    """One device context (tfhe_ctx): keys resident on one GPU, batch entry points."""
+
+    def __init__(self, params, device=0):
+        self._lib = load()
+        self.params = params
+        n, N, k, l, b, t, g, parties = params.engine_tuple()
+        self.n, self.N, self.k, self.parties = n, N, k, parties
+        p = TfheParams(n, N, k, l, b, t, g, parties)
+        h = C.c_void_p()
+        rc = self._lib.tfhe_ctx_create(C.byref(p), int(device), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self._lib.tfhe_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tfhe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self._lib.tfhe_last_error(self._h).decode())
+
+    # ---- keys ----
+    def load_bootstrap_key(self, bk_i32):
+        bk = _i32c(bk_i32)
+        l = self.params.bs_decomp_length
+        want = self.n * l * (self.k + 1) ** 2 * self.N
+        if bk.size != want:
+            raise ValueError(f"bootstrap key has {bk.size} words, expected {want}")
+        self._check(self._lib.tfhe_load_bootstrap_key_i32(self._h, _ptr(bk)))
+
+    def load_bootstrap_key_spectra(self, spectra):
+        s = np.ascontiguousarray(spectra, dtype=np.complex128)
+        l = self.params.bs_decomp_length
+        want = self.n * l * (self.k + 1) ** 2 * (self.N // 2)
+        if s.size != want:
+            raise ValueError(f"bootstrap key spectra have {s.size} values, expected {want}")
+        self._check(self._lib.tfhe_load_bootstrap_key_c128(self._h, _ptr(s)))
+
+    def load_keyswitch_key(self, ks):
+        ks = _i32c(ks)
+        p = self.params
+        want = self.k * self.N * p.ks_decomp_length * ((1 << p.ks_log2_base) - 1) * (self.n + 1)
+        if ks.size != want:
+            raise ValueError(f"keyswitch key has {ks.size} words, expected {want}")
+        self._check(self._lib.tfhe_load_keyswitch_key(self._h, _ptr(ks)))
+
+    # ---- hot path, host buffers ----
+    def gates(self, opcodes, in0, in1=None, in2=None):
+        ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
+        B = ops.size
+        in0, in1, in2 = _i32c(in0), _i32c(in1), _i32c(in2)
+        for a in (in0, in1, in2):
+            if a is not None and a.shape != (B, self.n + 1):
+                raise ValueError(f"operand shape {a.shape}, expected {(B, self.n + 1)}")
+        out = np.empty((B, self.n + 1), np.int32)
+        self._check(self._lib.tfhe_gates_batch(self._h, _ptr(ops), _ptr(in0), _ptr(in1), _ptr(in2), _ptr(out), B))
+        return out
+
+    def gates_dev(self, opcodes, d_in0, d_in1, d_in2, d_out, B, stream=0):
+        """Device-pointer variant: operands are integer device addresses (e.g. torch tensor .data_ptr())."""
+        ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
+        assert ops.size == B
+        self._check(self._lib.tfhe_gates_batch_dev(self._h, _ptr(ops), d_in0 or None, d_in1 or None,
+                                                   d_in2 or None, d_out, B, stream or None))
+
+    def bootstrap(self, mu, x, with_keyswitch=True):
+        x = _i32c(x)
+        B = x.shape[0]
+        width = self.n + 1 if with_keyswitch else self.k * self.N + 1
+        out = np.empty((B, width), np.int32)
+        self._check(self._lib.tfhe_bootstrap_batch(self._h, int(mu), _ptr(x), _ptr(out), B, 1 if with_keyswitch else 0))
+        return out
+
+    def keyswitch(self, x):
+        x = _i32c(x)
+        B = x.shape[0]
+        if x.shape[1] != self.k * self.N + 1:
+            raise ValueError("keyswitch input must be [B][k*N+1]")
+        out = np.empty((B, self.n + 1), np.int32)
+        self._check(self._lib.tfhe_keyswitch_batch(self._h, _ptr(x), _ptr(out), B))
+        return out
+
+    # ---- multi-key ----
+    def mk_load_bootstrap_key(self, bk_i32, parties):
+        bk = _i32c(bk_i32)
+        self._check(self._lib.tfhe_mk_load_bootstrap_key_i32(self._h, _ptr(bk), int(parties)))
+
+    def mk_load_keyswitch_key(self, ks, parties):
+        ks = _i32c(ks)
+        self._check(self._lib.tfhe_mk_load_keyswitch_key(self._h, _ptr(ks), int(parties)))
+
+    def mk_gate_nand(self, in0, in1):
+        in0, in1 = _i32c(in0), _i32c(in1)
+        out = np.empty_like(in0)
+        self._check(self._lib.tfhe_mk_gate_nand_batch(self._h, _ptr(in0), _ptr(in1), _ptr(out), in0.shape[0]))
+        return out
+
+    # ---- measurement ----
+    def last_timing_ms(self, which):
+        ms = C.c_float(0)
+        self._check(self._lib.tfhe_last_timing_ms(self._h, int(which), C.byref(ms)))
+        return float(ms.value)
+
+    def last_rotation_count(self):
+        return int(self._lib.tfhe_last_rotation_count(self._h))
+
+    def set_option(self, name, value):
+        self._check(self._lib.tfhe_set_option(self._h, name.encode(), int(value)))

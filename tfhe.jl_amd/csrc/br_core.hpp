@@ -1,0 +1,253 @@
+// br_core.hpp — per-lane building blocks of the blind-rotate kernel (gfx950, wave64).
+//
+// One 64-lane wave owns one TLWE accumulator for all n CMUX steps.  A polynomial of N = 1024
+// coefficients is folded into M = 512 complex points (the reference's transform,
+// polynomials.jl:106-132); lane t holds points t + 64 r (r = 0..7), i.e. coefficients t + 64 m
+// (m = 0..15).  The 512-point FFT is three radix-8 passes in registers with two transposes through
+// a padded LDS exchange buffer.  Output order of the forward transform is the fixed permutation
+//     lane L, register k2  <->  frequency (L >> 3) + 8 (L & 7) + 64 k2
+// which the inverse transform consumes unchanged and the bootstrapping key is stored in.
+//
+// Everything here is plain C++ (TFHE_HD) so the same lane code can be executed lane by lane on
+// the host (tests/host_sim) as well as in the HIP kernels.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TFHE_HD __host__ __device__ __forceinline__
+typedef double2 cplx;
+#else
+#define TFHE_HD inline
+struct cplx { double x, y; };
+#endif
+
+namespace tfhe {
+
+constexpr int kWave = 64;
+constexpr int kN = 1024;          // polynomial degree handled by this build of the core
+constexpr int kM = kN / 2;        // complex points per polynomial
+constexpr int kPts = kM / kWave;  // 8 complex points per lane
+constexpr int kXchElems = 576;    // padded exchange buffer, in cplx (8 rows x 72)
+
+TFHE_HD cplx mk(double re, double im) { cplx c; c.x = re; c.y = im; return c; }
+TFHE_HD cplx cadd(cplx a, cplx b) { return mk(a.x + b.x, a.y + b.y); }
+TFHE_HD cplx csub(cplx a, cplx b) { return mk(a.x - b.x, a.y - b.y); }
+// a * b
+TFHE_HD cplx cmul(cplx a, cplx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+TFHE_HD cplx cmulc(cplx a, cplx b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+// acc + a * b
+TFHE_HD cplx cfma(cplx a, cplx b, cplx acc)
+{
+    return mk(acc.x + a.x * b.x - a.y * b.y, acc.y + a.x * b.y + a.y * b.x);
+}
+
+// 8-point DFT in registers, natural order in and out.  INV = false: e^{-2 pi i rq/8}.
+// 52 double-precision operations: the 1/sqrt(2) of the odd outputs rides on the final FMAs.
+template <bool INV>
+TFHE_HD void dft8(cplx (&x)[8])
+{
+    const double s = 0.70710678118654752440;
+    const cplx a0 = cadd(x[0], x[4]), a1 = cadd(x[1], x[5]), a2 = cadd(x[2], x[6]), a3 = cadd(x[3], x[7]);
+    const cplx t0 = csub(x[0], x[4]), t1 = csub(x[1], x[5]), t2 = csub(x[2], x[6]), t3 = csub(x[3], x[7]);
+    cplx b1, b2, b3;  // b1, b3 lack their 1/sqrt(2)
+    if (!INV) {
+        b1 = mk(t1.x + t1.y, t1.y - t1.x);     // t1 * (1 - i)
+        b2 = mk(t2.y, -t2.x);                  // t2 * (-i)
+        b3 = mk(t3.y - t3.x, -(t3.x + t3.y));  // t3 * (-1 - i)
+    } else {
+        b1 = mk(t1.x - t1.y, t1.x + t1.y);     // t1 * (1 + i)
+        b2 = mk(-t2.y, t2.x);                  // t2 * (+i)
+        b3 = mk(-(t3.x + t3.y), t3.x - t3.y);  // t3 * (-1 + i)
+    }
+    {   // even outputs: DFT4(a)
+        const cplx c0 = cadd(a0, a2), c1 = cadd(a1, a3), d0 = csub(a0, a2), e = csub(a1, a3);
+        const cplx d1 = INV ? mk(-e.y, e.x) : mk(e.y, -e.x);
+        x[0] = cadd(c0, c1); x[4] = csub(c0, c1); x[2] = cadd(d0, d1); x[6] = csub(d0, d1);
+    }
+    {   // odd outputs: DFT4(b)
+        const cplx c0 = cadd(t0, b2), d0 = csub(t0, b2), c1 = cadd(b1, b3), e = csub(b1, b3);
+        const cplx d1 = INV ? mk(-e.y, e.x) : mk(e.y, -e.x);
+        x[1] = mk(c0.x + s * c1.x, c0.y + s * c1.y);
+        x[5] = mk(c0.x - s * c1.x, c0.y - s * c1.y);
+        x[3] = mk(d0.x + s * d1.x, d0.y + s * d1.y);
+        x[7] = mk(d0.x - s * d1.x, d0.y - s * d1.y);
+    }
+}
+
+// Twiddle tables (device global memory / host arrays), built by make_tables().
+struct Tables {
+    const cplx *tw1;    // [8][64]  e^{-2 pi i t q / 512}          (row 0 unused = 1)
+    const cplx *tw2;    // [8][8]   e^{-2 pi i t' q2 / 64}
+    const cplx *twist;  // [8][64]  e^{-i pi (t + 64 r) / N}       polynomials.jl:53
+};
+
+// ---- LDS exchange addressing (units of cplx) ---------------------------------------------------
+// exchange 1: [q][t] rows of 64 padded to 72; exchange 2: transposes inside 8-lane groups.
+TFHE_HD int x1_a(int lane, int q) { return q * 72 + lane; }                          // lane t, reg q
+TFHE_HD int x1_b(int lane, int s) { return (lane >> 3) * 72 + (lane & 7) + 8 * s; }  // lane (q',t'), reg s
+TFHE_HD int x2_w(int lane, int q2) { return (lane >> 3) * 72 + q2 * 9 + (lane & 7); }
+TFHE_HD int x2_r(int lane, int v) { return (lane >> 3) * 72 + (lane & 7) * 9 + v; }
+
+// ---- forward transform, split at the two LDS round trips ---------------------------------------
+TFHE_HD void fwd_pass_a(int lane, cplx (&x)[8], const Tables &T)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], T.tw1[q * 64 + lane]);
+}
+TFHE_HD void fwd_pass_b(int lane, cplx (&x)[8], const Tables &T)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], T.tw2[q * 8 + (lane & 7)]);
+}
+TFHE_HD void fwd_pass_c(cplx (&x)[8]) { dft8<false>(x); }
+
+// ---- inverse transform (unnormalised; the 1/M lives in the key spectra) -------------------------
+TFHE_HD void inv_pass_c(cplx (&x)[8]) { dft8<true>(x); }
+TFHE_HD void inv_pass_b(int lane, cplx (&x)[8], const Tables &T)
+{
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], T.tw2[q * 8 + (lane & 7)]);
+    dft8<true>(x);
+}
+TFHE_HD void inv_pass_a(int lane, cplx (&x)[8], const Tables &T)
+{
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], T.tw1[q * 64 + lane]);
+    dft8<true>(x);
+}
+
+// exchange helpers on a generic "LDS" pointer
+TFHE_HD void x1_store_a(int lane, const cplx (&x)[8], cplx *xch)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) xch[x1_a(lane, q)] = x[q];
+}
+TFHE_HD void x1_load_a(int lane, cplx (&x)[8], const cplx *xch)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = xch[x1_a(lane, q)];
+}
+TFHE_HD void x1_store_b(int lane, const cplx (&x)[8], cplx *xch)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) xch[x1_b(lane, s)] = x[s];
+}
+TFHE_HD void x1_load_b(int lane, cplx (&x)[8], const cplx *xch)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) x[s] = xch[x1_b(lane, s)];
+}
+TFHE_HD void x2_store(int lane, const cplx (&x)[8], cplx *xch)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) xch[x2_w(lane, q)] = x[q];
+}
+TFHE_HD void x2_load(int lane, cplx (&x)[8], const cplx *xch)
+{
+#pragma unroll
+    for (int v = 0; v < 8; v++) x[v] = xch[x2_r(lane, v)];
+}
+
+// ---- torus / integer pieces ---------------------------------------------------------------------
+// Low 32 bits of round(v) for |v| < 2^51: adding 1.5 * 2^52 leaves round(v) in the low mantissa bits
+// in two's complement.  Equivalent to polynomials.jl:115-116 (round(Int64, x) then the low 32 bits).
+TFHE_HD int32_t round_to_torus32(double v)
+{
+    const double t = v + 6755399441055744.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)__double2loint(t);
+#else
+    uint64_t u;
+    memcpy(&u, &t, 8);
+    return (int32_t)(uint32_t)u;
+#endif
+}
+
+// Gadget decomposition constants (tgsw.jl:8-21, 99-117).
+struct Gadget {
+    int32_t offset;     // sum_p 2^(32 - p beta) * 2^(beta-1), wrapped
+    int32_t log2_base;  // beta
+    int32_t mask;       // 2^beta - 1
+    int32_t half;       // 2^(beta-1)
+};
+TFHE_HD Gadget make_gadget(int l, int log2_base)
+{
+    Gadget g;
+    uint32_t sum = 0;
+    for (int p = 1; p <= l; p++) sum += 1u << (32 - p * log2_base);
+    g.offset = (int32_t)(sum * (1u << (log2_base - 1)));
+    g.log2_base = log2_base;
+    g.mask = (int32_t)((1u << log2_base) - 1);
+    g.half = (int32_t)(1u << (log2_base - 1));
+    return g;
+}
+// digit p (1-based) of an already offset coefficient (tgsw.jl:115-116)
+TFHE_HD int32_t gadget_digit(int32_t c_plus_offset, int p, const Gadget &g)
+{
+    return ((c_plus_offset >> (32 - p * g.log2_base)) & g.mask) - g.half;
+}
+
+// (X^a - 1) * acc for this lane's 16 coefficients, plus the decomposition offset:
+//   temp[m] = rot(acc)[t + 64 m] - acc[t + 64 m] + offset      (bootstrap.jl:21, tlwe.jl:88-93)
+// acc_lds holds the whole polynomial; cur[] is this lane's copy of its own coefficients.
+TFHE_HD void rotate_sub(int lane, int a_mod_2N, const int32_t *acc_lds, const int32_t (&cur)[16],
+                        int32_t offset, int32_t (&temp)[16])
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int idx = (lane + 64 * m - a_mod_2N) & (2 * kN - 1);
+        const int32_t v = acc_lds[idx & (kN - 1)];
+        const uint32_t r = (idx & kN) ? 0u - (uint32_t)v : (uint32_t)v;
+        temp[m] = (int32_t)(r - (uint32_t)cur[m] + (uint32_t)offset);
+    }
+}
+
+// digit polynomial p of temp, folded and twisted: x[r] = (d[t+64r] - i d[t+64r+512]) * twist[r][t]
+// (polynomials.jl:110)
+TFHE_HD void load_digits(int lane, const int32_t (&temp)[16], int p, const Gadget &g, const Tables &T,
+                         cplx (&x)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double lo = (double)gadget_digit(temp[r], p, g);
+        const double hi = (double)gadget_digit(temp[r + 8], p, g);
+        const cplx w = T.twist[r * 64 + lane];
+        x[r] = mk(lo * w.x + hi * w.y, lo * w.y - hi * w.x);
+    }
+}
+
+// fold + twist of a full-range Int32 polynomial (key preparation; same formula as load_digits)
+TFHE_HD void load_poly(int lane, const int32_t *poly, const Tables &T, cplx (&x)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double lo = (double)poly[lane + 64 * r];
+        const double hi = (double)poly[lane + 64 * r + kM];
+        const cplx w = T.twist[r * 64 + lane];
+        x[r] = mk(lo * w.x + hi * w.y, lo * w.y - hi * w.x);
+    }
+}
+
+// after the inverse transform: conj(y) * twist, real -> coefficient t+64r, imag -> t+64r+512
+// (polynomials.jl:127-129), rounded and added into the accumulator (bootstrap.jl:22).
+TFHE_HD void untwist_add(int lane, const cplx (&y)[8], const Tables &T, int32_t (&acc)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const cplx w = T.twist[r * 64 + lane];
+        const double re = y[r].x * w.x + y[r].y * w.y;
+        const double im = y[r].x * w.y - y[r].y * w.x;
+        acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
+        acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(im));
+    }
+}
+
+// Frequency index held by (lane, reg) after the forward transform.
+TFHE_HD int freq_of(int lane, int k2) { return (lane >> 3) + 8 * (lane & 7) + 64 * k2; }
+
+}  // namespace tfhe

@@ -1,0 +1,850 @@
+// tfhe_engine.hip — MI355X (gfx950) TFHE gate-bootstrapping engine: kernels, context, C ABI.
+//
+// Pipeline of one batch call (tfhe_gates_batch*):
+//   prologue_kernel       gate affine prologue (gates.jl) + modulus switch (bootstrap.jl:74-75)
+//   blind_rotate_kernel   one wave per blind rotation, accumulator resident in LDS/registers for
+//                         all n CMUX steps (bootstrap.jl:19-59, tgsw.jl:99-129, polynomials.jl),
+//                         fused test-vector init and sample extraction (tlwe.jl:55-59)
+//   keyswitch_kernel      digit-gather-subtract keyswitch (keyswitch.jl:45-80), MUX add fused
+//   trivial_gates_kernel  NOT / CONSTANT / COPY (gates.jl:76-93)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tfhe_mi355x.h"
+#include "br_core.hpp"
+
+using namespace tfhe;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+
+// Per-opcode affine prologue  t = (0, cst) + sx*x + sy*y  [* 2 for XOR/XNOR]   (gates.jl)
+struct GateForm {
+    int32_t cst;   // constant added to b
+    int8_t sx, sy; // +-1 coefficients (after the optional doubling)
+    int8_t mul2;   // (x + y) * 2 form (gates.jl:52,64)
+    int8_t use_z;  // second operand comes from in2 (MUX second half)
+};
+
+__host__ __device__ inline GateForm gate_form(int kind)
+{
+    // kind: opcode for plain gates; 100 = MUX first half (AND(x,y)), 101 = MUX second half (ANDNY(x,z))
+    const int32_t p8 = (int32_t)(1u << 29), p4 = (int32_t)(1u << 30);
+    switch (kind) {
+    case TFHE_GATE_NAND:  return {p8, -1, -1, 0, 0};
+    case TFHE_GATE_OR:    return {p8, 1, 1, 0, 0};
+    case TFHE_GATE_AND:   return {-p8, 1, 1, 0, 0};
+    case TFHE_GATE_XOR:   return {p4, 1, 1, 1, 0};
+    case TFHE_GATE_XNOR:  return {-p4, -1, -1, 1, 0};
+    case TFHE_GATE_NOR:   return {-p8, -1, -1, 0, 0};
+    case TFHE_GATE_ANDNY: return {-p8, -1, 1, 0, 0};
+    case TFHE_GATE_ANDYN: return {-p8, 1, -1, 0, 0};
+    case TFHE_GATE_ORNY:  return {p8, -1, 1, 0, 0};
+    case TFHE_GATE_ORYN:  return {p8, 1, -1, 0, 0};
+    case 100:             return {-p8, 1, 1, 0, 0};   // gates.jl:166
+    case 101:             return {-p8, -1, 1, 0, 1};  // gates.jl:170
+    default:              return {0, 0, 0, 0, 0};
+    }
+}
+
+// rot_gate[w] = gate index, rot_kind[w] = kind (see gate_form); writes bara[w][0..n] (barb last).
+__global__ void prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
+                                const int32_t *__restrict__ in2, const int32_t *__restrict__ rot_gate,
+                                const uint8_t *__restrict__ rot_kind, int32_t *__restrict__ bara, int n,
+                                int log2_2N)
+{
+    const int w = blockIdx.x;
+    const size_t g = (size_t)rot_gate[w];
+    const GateForm f = gate_form(rot_kind[w]);
+    const int32_t *x = in0 + g * (n + 1);
+    const int32_t *y = (f.use_z ? in2 : in1) + g * (n + 1);
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        uint32_t v;
+        if (f.mul2) {
+            v = ((uint32_t)x[i] + (uint32_t)y[i]) * 2u;
+            if (f.sx < 0) v = 0u - v;
+        } else {
+            const uint32_t xv = f.sx > 0 ? (uint32_t)x[i] : 0u - (uint32_t)x[i];
+            const uint32_t yv = f.sy > 0 ? (uint32_t)y[i] : 0u - (uint32_t)y[i];
+            v = xv + yv;
+        }
+        if (i == n) v += (uint32_t)f.cst;
+        // decode_message(v, 2N): numeric-functions.jl:31-34
+        const int32_t r = (int32_t)(v + (1u << (32 - log2_2N - 1))) >> (32 - log2_2N);
+        bara[(size_t)w * (n + 1) + i] = r;
+    }
+}
+
+// modulus switch only (tfhe_bootstrap_batch): bara[w][i] = decode_message(in[w][i], 2N)
+__global__ void modswitch_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ bara, int n, int log2_2N)
+{
+    const size_t w = blockIdx.x;
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        const uint32_t v = (uint32_t)in[w * (n + 1) + i];
+        bara[w * (n + 1) + i] = (int32_t)(v + (1u << (32 - log2_2N - 1))) >> (32 - log2_2N);
+    }
+}
+
+struct BrArgs {
+    const int32_t *bara;  // [R][n+1], barb last
+    const cplx *bk;       // [n][L][K1][K1][8][64] spectra, permuted order, scaled by 1/M
+    int32_t *ext;         // [R][(K1-1)*N + 1]
+    Tables T;
+    Gadget g;
+    int32_t n;
+    int32_t mu;
+};
+
+template <int K1>
+__device__ __forceinline__ void store_acc(int lane, const int32_t (&acc)[16], int32_t *acc_lds)
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) acc_lds[lane + 64 * m] = acc[m];
+}
+
+// One wave = one blind rotation + extraction.
+template <int L, int K1>
+__global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);            // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);        // [kXchElems]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+
+    // accum = (0, ..., 0, X^{-barb} * (mu, ..., mu))     bootstrap.jl:54-56,78 ; tlwe.jl:77-81
+    int32_t acc[K1][16];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int c = 0; c < K1 - 1; c++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) acc[c][m] = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc[K1 - 1][m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+#pragma unroll
+        for (int c = 0; c < K1; c++) store_acc<K1>(lane, acc[c], acc_lds + c * kN);
+    }
+    __syncthreads();
+
+    for (int i = 0; i < P.n; i++) {                                   // bootstrap.jl:33
+        const int a = bara[i] & (2 * kN - 1);
+        if (a == 0) continue;                                         // bootstrap.jl:34
+        const cplx *bki = P.bk + (size_t)i * (L * K1 * K1 * kM);
+        cplx out[K1][8];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
+
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[16];
+            rotate_sub(lane, a, acc_lds + c * kN, acc[c], P.g.offset, temp);   // bootstrap.jl:21
+#pragma unroll
+            for (int p = 1; p <= L; p++) {
+                cplx x[8];
+                load_digits(lane, temp, p, P.g, P.T, x);                      // tgsw.jl:126-127
+                fwd_pass_a(lane, x, P.T);
+                x1_store_a(lane, x, xch);
+                __syncthreads();
+                x1_load_b(lane, x, xch);
+                __syncthreads();
+                fwd_pass_b(lane, x, P.T);
+                x2_store(lane, x, xch);
+                __syncthreads();
+                x2_load(lane, x, xch);
+                __syncthreads();
+                fwd_pass_c(x);
+                // out[co] += D[p, c] .* BK_i[p, c].a[co]                      tgsw.jl:128
+                const cplx *kp = bki + (size_t)((p - 1) * K1 + c) * K1 * kM + lane;
+#pragma unroll
+                for (int co = 0; co < K1; co++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kp[(co * 8 + k2) * 64], out[co][k2]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < K1; co++) {                                      // polynomials.jl:119-132
+            inv_pass_c(out[co]);
+            x2_store(lane, out[co], xch);
+            __syncthreads();
+            x2_load(lane, out[co], xch);
+            __syncthreads();
+            inv_pass_b(lane, out[co], P.T);
+            x1_store_b(lane, out[co], xch);
+            __syncthreads();
+            x1_load_a(lane, out[co], xch);
+            __syncthreads();
+            inv_pass_a(lane, out[co], P.T);
+            untwist_add(lane, out[co], P.T, acc[co]);                          // bootstrap.jl:22
+            store_acc<K1>(lane, acc[co], acc_lds + co * kN);
+        }
+        __syncthreads();
+    }
+
+    // tlwe_extract_sample (tlwe.jl:55-59): a'[0] = p[0], a'[m] = -p[N-m]; b' = body[0]
+    int32_t *ext = P.ext + w * ((K1 - 1) * kN + 1);
+#pragma unroll
+    for (int c = 0; c < K1 - 1; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int j = lane + 64 * m;
+            if (j == 0) ext[c * kN] = acc[c][m];
+            else ext[c * kN + kN - j] = (int32_t)(0u - (uint32_t)acc[c][m]);
+        }
+    if (lane == 0) ext[(K1 - 1) * kN] = acc[K1 - 1][0];
+}
+
+// Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
+// (the analogue of forward_transform.(bk), bootstrap.jl:12)
+__global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
+{
+    __shared__ __attribute__((aligned(16))) cplx xch[kXchElems];
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    cplx x[8];
+    load_poly(lane, bk_i32 + q * kN, T, x);
+    fwd_pass_a(lane, x, T);
+    x1_store_a(lane, x, xch);
+    __syncthreads();
+    x1_load_b(lane, x, xch);
+    __syncthreads();
+    fwd_pass_b(lane, x, T);
+    x2_store(lane, x, xch);
+    __syncthreads();
+    x2_load(lane, x, xch);
+    __syncthreads();
+    fwd_pass_c(x);
+    const double s = 1.0 / kM;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) out[q * kM + k2 * 64 + lane] = mk(x[k2].x * s, x[k2].y * s);
+}
+
+// The reference's stored spectra (natural frequency order, polynomials.jl:106-112) -> engine order.
+__global__ __launch_bounds__(64) void bk_permute_c128_kernel(const cplx *__restrict__ in, cplx *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const double s = 1.0 / kM;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const cplx v = in[q * kM + freq_of(lane, k2)];
+        out[q * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
+    }
+}
+
+// keyswitch.jl:45-80.  One workgroup per output sample; thread w owns words w, w + blockDim, ...
+// Input sample = ext[e0] (+ ext[e1] + (0, 2^29) for MUX, gates.jl:174).
+struct KsArgs {
+    const int32_t *ext;     // [R][kN+1]
+    const int32_t *ks;      // [kN][t][base-1][n+1]
+    const int32_t *e0;      // [G] index into ext
+    const int32_t *e1;      // [G] second index or -1
+    const int32_t *dst;     // [G] output gate index (NULL: identity)
+    int32_t *out;           // [B][n+1]
+    int32_t n, kN, t, log2_base;
+};
+
+template <int WPT>  // words per thread
+__global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
+{
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n1 = P.n + 1;
+    const int32_t *x0 = P.ext + (size_t)P.e0[g] * (P.kN + 1);
+    const int e1 = P.e1 ? P.e1[g] : -1;
+    const int32_t *x1 = e1 >= 0 ? P.ext + (size_t)e1 * (P.kN + 1) : nullptr;
+    const int base1 = (1 << P.log2_base) - 1;
+    const uint32_t prec_offset = 1u << (32 - (1 + P.log2_base * P.t));       // keyswitch.jl:58
+
+    uint32_t accw[WPT];
+#pragma unroll
+    for (int u = 0; u < WPT; u++) accw[u] = 0;
+
+    for (int i = 0; i < P.kN; i++) {
+        uint32_t ai = (uint32_t)x0[i];
+        if (x1) ai += (uint32_t)x1[i];
+        const int32_t aibar = (int32_t)(ai + prec_offset);                  // keyswitch.jl:59
+        const int32_t *rows_i = P.ks + (size_t)i * P.t * base1 * n1;
+        for (int j = 1; j <= P.t; j++) {
+            const int d = (aibar >> (32 - j * P.log2_base)) & base1;         // keyswitch.jl:65-67
+            if (d != 0) {                                                    // keyswitch.jl:73
+                const int32_t *row = rows_i + (size_t)((j - 1) * base1 + (d - 1)) * n1;
+#pragma unroll
+                for (int u = 0; u < WPT; u++) {
+                    const int wd = tid + u * 256;
+                    if (wd < n1) accw[u] -= (uint32_t)row[wd];               // keyswitch.jl:74
+                }
+            }
+        }
+    }
+    const size_t og = P.dst ? (size_t)P.dst[g] : (size_t)g;
+    int32_t *o = P.out + og * n1;
+#pragma unroll
+    for (int u = 0; u < WPT; u++) {
+        const int wd = tid + u * 256;
+        if (wd < n1) {
+            uint32_t v = accw[u];
+            if (wd == P.n) {                                                 // keyswitch.jl:50
+                v += (uint32_t)x0[P.kN];
+                if (x1) v += (uint32_t)x1[P.kN] + (1u << 29);                // gates.jl:174
+            }
+            o[wd] = (int32_t)v;
+        }
+    }
+}
+
+// gate_not / gate_constant / copy (gates.jl:76-93)
+__global__ void trivial_gates_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ gates,
+                                     const uint8_t *__restrict__ ops, int32_t *__restrict__ out, int n)
+{
+    const size_t g = (size_t)gates[blockIdx.x];
+    const int op = ops[blockIdx.x];
+    for (int i = threadIdx.x; i <= n; i += blockDim.x) {
+        uint32_t v;
+        if (op == TFHE_GATE_NOT) v = 0u - (uint32_t)in0[g * (n + 1) + i];
+        else if (op == TFHE_GATE_COPY) v = (uint32_t)in0[g * (n + 1) + i];
+        else v = (i == n) ? (op == TFHE_GATE_CONST1 ? (1u << 29) : 0u - (1u << 29)) : 0u;
+        out[g * (n + 1) + i] = (int32_t)v;
+    }
+}
+
+// extracted sample copy-out for tfhe_bootstrap_batch(with_keyswitch = 0) is a plain memcpy.
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct tfhe_ctx {
+    tfhe_params P{};
+    int device = 0;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
+    bool timing_valid = false;
+    int64_t last_rotations = 0;
+
+    // tables
+    cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
+    Tables T{};
+    Gadget g{};
+
+    // keys
+    cplx *d_bk = nullptr;       size_t bk_polys = 0;
+    int32_t *d_ks = nullptr;
+    bool have_bk = false, have_ks = false;
+
+    // workspaces
+    DevBuf bara, ext, map, io[4];
+    void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
+    hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
+
+    int set_err(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return (ctx)->set_err(TFHE_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static void build_tables(std::vector<cplx> &h)
+{
+    // tw1[q][t] = e^{-2 pi i t q/512}; tw2[q][t'] = e^{-2 pi i t' q/64}; twist[r][t] = e^{-i pi (t+64r)/N}
+    const long double pi = 3.14159265358979323846264338327950288L;
+    h.resize(512 + 64 + 512);
+    for (int q = 0; q < 8; q++)
+        for (int t = 0; t < 64; t++) {
+            const long double a = -2.0L * pi * (long double)(t * q) / 512.0L;
+            h[q * 64 + t] = mk((double)cosl(a), (double)sinl(a));
+        }
+    for (int q = 0; q < 8; q++)
+        for (int t = 0; t < 8; t++) {
+            const long double a = -2.0L * pi * (long double)(t * q) / 64.0L;
+            h[512 + q * 8 + t] = mk((double)cosl(a), (double)sinl(a));
+        }
+    for (int r = 0; r < 8; r++)
+        for (int t = 0; t < 64; t++) {
+            const long double a = -pi * (long double)(t + 64 * r) / (long double)kN;
+            h[576 + r * 64 + t] = mk((double)cosl(a), (double)sinl(a));
+        }
+}
+
+static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
+
+extern "C" {
+
+int32_t tfhe_abi_version(void) { return TFHE_MI355X_ABI_VERSION; }
+
+int32_t tfhe_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+const char *tfhe_last_error(const tfhe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx **out_ctx)
+{
+    if (!params || !out_ctx) { g_create_error = "tfhe_ctx_create: NULL argument"; return TFHE_ERR_INVALID_ARG; }
+    *out_ctx = nullptr;
+    const tfhe_params &p = *params;
+    char buf[256];
+    auto fail = [&](int code, const char *msg) { g_create_error = msg; return code; };
+    if (p.n < 1 || p.N < 2 || (p.N & (p.N - 1)) || p.k < 1 || p.bs_l < 1 || p.bs_log2_base < 1 || p.ks_t < 1 ||
+        p.ks_log2_base < 1 || p.parties < 1)
+        return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: parameters must be positive and N a power of two");
+    if (p.bs_l * p.bs_log2_base > 32) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: bs_l * bs_log2_base > 32");
+    if (p.ks_t * p.ks_log2_base > 31) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: ks_t * ks_log2_base > 31");
+    if (p.N != kN) {
+        snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d only (got %d)", kN, p.N);
+        return fail(TFHE_ERR_UNSUPPORTED, buf);
+    }
+    if (p.k != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 only");
+    if (p.bs_l > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 unsupported");
+    if (p.n + 1 > 1024) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: lwe_size + 1 > 1024 unsupported");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(buf, sizeof buf, "tfhe_ctx_create: no HIP device available (%s)", hipGetErrorString(e));
+        return fail(TFHE_ERR_DEVICE, buf);
+    }
+    if (device_id < 0 || device_id >= ndev) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: device_id out of range");
+
+    tfhe_ctx *c = new tfhe_ctx();
+    c->P = p;
+    c->device = device_id;
+    c->g = make_gadget(p.bs_l, p.bs_log2_base);
+    auto bail = [&](hipError_t err, const char *what) {
+        snprintf(buf, sizeof buf, "tfhe_ctx_create: %s failed: %s", what, hipGetErrorString(err));
+        g_create_error = buf;
+        tfhe_ctx_destroy(c);
+        return (int32_t)TFHE_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->map_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    std::vector<cplx> h;
+    build_tables(h);
+    if ((e = hipMalloc((void **)&c->d_tables, h.size() * sizeof(cplx))) != hipSuccess) return bail(e, "hipMalloc(tables)");
+    if ((e = hipMemcpy(c->d_tables, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(tables)");
+    c->T.tw1 = c->d_tables;
+    c->T.tw2 = c->d_tables + 512;
+    c->T.twist = c->d_tables + 576;
+    *out_ctx = c;
+    return TFHE_OK;
+}
+
+void tfhe_ctx_destroy(tfhe_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_bk) (void)hipFree(c->d_bk);
+    if (c->d_ks) (void)hipFree(c->d_ks);
+    c->bara.release(); c->ext.release(); c->map.release();
+    for (auto &b : c->io) b.release();
+    if (c->h_map) (void)hipHostFree(c->h_map);
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->map_ev) (void)hipEventDestroy(c->map_ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out)
+{
+    if (!ctx || !out) return TFHE_ERR_INVALID_ARG;
+    *out = ctx->P;
+    return TFHE_OK;
+}
+
+static size_t bk_poly_count(const tfhe_params &p) { return (size_t)p.n * p.bs_l * (p.k + 1) * (p.k + 1); }
+
+static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (!host) return c->set_err(TFHE_ERR_INVALID_ARG, "load_bootstrap_key: NULL key pointer");
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_bootstrap_key: context is multi-key, use tfhe_mk_load_*");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npolys = bk_poly_count(c->P);
+    if (c->d_bk) { (void)hipFree(c->d_bk); c->d_bk = nullptr; c->have_bk = false; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_bk, npolys * kM * sizeof(cplx)));
+    void *d_in = nullptr;
+    HIP_TRY(c, hipMalloc(&d_in, bytes_in));
+    hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        if (is_c128)
+            hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_bk);
+        else
+            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_bk, c->T);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    if (e != hipSuccess) return c->set_err(TFHE_ERR_DEVICE, "load_bootstrap_key: %s", hipGetErrorString(e));
+    c->bk_polys = npolys;
+    c->have_bk = true;
+    return TFHE_OK;
+}
+
+int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return load_bk_common(c, bk, bk_poly_count(c->P) * kN * sizeof(int32_t), false);
+}
+
+int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return load_bk_common(c, bk_spectra, bk_poly_count(c->P) * kM * sizeof(cplx), true);
+}
+
+static size_t ks_word_count(const tfhe_params &p)
+{
+    return (size_t)p.k * p.N * p.ks_t * ((1u << p.ks_log2_base) - 1) * (size_t)(p.n + 1);
+}
+
+int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "load_keyswitch_key: NULL key pointer");
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_keyswitch_key: context is multi-key, use tfhe_mk_load_*");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = ks_word_count(c->P) * sizeof(int32_t);
+    if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; c->have_ks = false; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_ks, bytes));
+    HIP_TRY(c, hipMemcpy(c->d_ks, ks, bytes, hipMemcpyHostToDevice));
+    c->have_ks = true;
+    return TFHE_OK;
+}
+
+// ---- launch helpers ------------------------------------------------------------------------------
+static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
+{
+    BrArgs a;
+    a.bara = (const int32_t *)c->bara.p;
+    a.bk = c->d_bk;
+    a.ext = (int32_t *)c->ext.p;
+    a.T = c->T;
+    a.g = c->g;
+    a.n = c->P.n;
+    a.mu = mu;
+    const size_t lds = 2 * kN * 4 + kXchElems * sizeof(cplx);
+    switch (c->P.bs_l) {
+    case 1: hipLaunchKernelGGL((blind_rotate_kernel<1, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((blind_rotate_kernel<2, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((blind_rotate_kernel<3, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((blind_rotate_kernel<4, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
+    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return TFHE_OK;
+}
+
+static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const int32_t *e1, const int32_t *dst,
+                                const int32_t *ext, int32_t *out, hipStream_t s)
+{
+    KsArgs k;
+    k.ext = ext;
+    k.ks = c->d_ks;
+    k.e0 = e0; k.e1 = e1; k.dst = dst;
+    k.out = out;
+    k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
+    const int n1 = c->P.n + 1;
+    if (n1 <= 256) hipLaunchKernelGGL((keyswitch_kernel<1>), dim3((unsigned)G), dim3(256), 0, s, k);
+    else if (n1 <= 512) hipLaunchKernelGGL((keyswitch_kernel<2>), dim3((unsigned)G), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((keyswitch_kernel<4>), dim3((unsigned)G), dim3(256), 0, s, k);
+    HIP_TRY(c, hipGetLastError());
+    return TFHE_OK;
+}
+
+static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
+{
+    if (c->map_pending) {   // the previous call's H2D copy of the staging block must have been consumed
+        HIP_TRY(c, hipEventSynchronize(c->map_ev));
+        c->map_pending = false;
+    }
+    if (bytes <= c->h_map_cap) return TFHE_OK;
+    if (c->h_map) (void)hipHostFree(c->h_map);
+    c->h_map = nullptr; c->h_map_cap = 0;
+    HIP_TRY(c, hipHostMalloc(&c->h_map, bytes + bytes / 4 + 256, hipHostMallocDefault));
+    c->h_map_cap = bytes + bytes / 4 + 256;
+    return TFHE_OK;
+}
+
+int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *d_in0, const int32_t *d_in1,
+                             const int32_t *d_in2, int32_t *d_out, int64_t B, void *stream)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!opcodes || !d_out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
+    if (B == 0) { c->timing_valid = false; c->last_rotations = 0; return TFHE_OK; }
+    if (B > (int64_t)1 << 30) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: B too large");
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_batch: context is multi-key");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+
+    // classify gates: rotations (R), keyswitches (G), trivial (T)
+    size_t R = 0, G = 0, Tn = 0;
+    bool need1 = false, need2 = false, need0 = false;
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: bad opcode %d at gate %lld", op, (long long)g);
+        if (op == TFHE_GATE_MUX) { R += 2; G += 1; need0 = need1 = need2 = true; }
+        else if (op == TFHE_GATE_NOT || op == TFHE_GATE_COPY) { Tn++; need0 = true; }
+        else if (op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1) { Tn++; }
+        else { R += 1; G += 1; need0 = need1 = true; }
+    }
+    if ((need0 && !d_in0) || (need1 && !d_in1) || (need2 && !d_in2))
+        return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: an operand array required by the opcodes is NULL");
+    if (R > 0 && (!c->have_bk || !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "gates_batch: bootstrapping/keyswitch key not loaded");
+
+    // index maps, one pinned staging block: rot_gate[R] | ks_e0[G] | ks_e1[G] | ks_dst[G] | triv_gate[T] | rot_kind[R] | triv_op[T]
+    const size_t map_bytes = (R + 3 * G + Tn) * 4 + R + Tn;
+    int32_t rc = ensure_host_map(c, map_bytes);
+    if (rc) return rc;
+    int32_t *h_rot_gate = (int32_t *)c->h_map;
+    int32_t *h_e0 = h_rot_gate + R, *h_e1 = h_e0 + G, *h_dst = h_e1 + G, *h_triv = h_dst + G;
+    uint8_t *h_kind = (uint8_t *)(h_triv + Tn), *h_top = h_kind + R;
+    {
+        size_t r = 0, k = 0, t = 0;
+        for (int64_t g = 0; g < B; g++) {
+            const int op = opcodes[g];
+            if (op == TFHE_GATE_MUX) {
+                h_rot_gate[r] = (int32_t)g; h_kind[r] = 100;
+                h_rot_gate[r + 1] = (int32_t)g; h_kind[r + 1] = 101;
+                h_e0[k] = (int32_t)r; h_e1[k] = (int32_t)(r + 1); h_dst[k] = (int32_t)g;
+                r += 2; k++;
+            } else if (op == TFHE_GATE_NOT || op == TFHE_GATE_COPY || op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1) {
+                h_triv[t] = (int32_t)g; h_top[t] = (uint8_t)op; t++;
+            } else {
+                h_rot_gate[r] = (int32_t)g; h_kind[r] = (uint8_t)op;
+                h_e0[k] = (int32_t)r; h_e1[k] = -1; h_dst[k] = (int32_t)g;
+                r++; k++;
+            }
+        }
+    }
+    HIP_TRY(c, c->map.reserve(map_bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, map_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(c->map_ev, s));
+    c->map_pending = true;
+    const int32_t *d_rot_gate = (const int32_t *)c->map.p;
+    const int32_t *d_e0 = d_rot_gate + R, *d_e1 = d_e0 + G, *d_dst = d_e1 + G, *d_triv = d_dst + G;
+    const uint8_t *d_kind = (const uint8_t *)(d_triv + Tn), *d_top = d_kind + R;
+
+    const int n = c->P.n, kNn = c->P.k * c->P.N;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    if (R > 0) {
+        HIP_TRY(c, c->bara.reserve(R * (size_t)(n + 1) * 4));
+        HIP_TRY(c, c->ext.reserve(R * (size_t)(kNn + 1) * 4));
+        hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)R), dim3(256), 0, s, d_in0, d_in1, d_in2, d_rot_gate, d_kind,
+                           (int32_t *)c->bara.p, n, ilog2i(2 * c->P.N));
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (R > 0) {
+        rc = launch_blind_rotate(c, R, (int32_t)(1u << 29), s);   // mu = encode_message(1, 8), gates.jl:17
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (G > 0) {
+        rc = launch_keyswitch(c, G, d_e0, d_e1, d_dst, (const int32_t *)c->ext.p, d_out, s);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    if (Tn > 0) {
+        hipLaunchKernelGGL(trivial_gates_kernel, dim3((unsigned)Tn), dim3(256), 0, s, d_in0, d_triv, d_top, d_out, n);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->timing_valid = true;
+    c->last_rotations = (int64_t)R;
+    return TFHE_OK;
+}
+
+int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
+                         const int32_t *in2, int32_t *out, int64_t B)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)B * (c->P.n + 1) * 4;
+    const int32_t *hin[3] = {in0, in1, in2};
+    int32_t *din[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; i++) {
+        if (!hin[i]) continue;
+        HIP_TRY(c, c->io[i].reserve(bytes));
+        HIP_TRY(c, hipMemcpyAsync(c->io[i].p, hin[i], bytes, hipMemcpyHostToDevice, c->stream));
+        din[i] = (int32_t *)c->io[i].p;
+    }
+    HIP_TRY(c, c->io[3].reserve(bytes));
+    int32_t rc = tfhe_gates_batch_dev(c, opcodes, din[0], din[1], din[2], (int32_t *)c->io[3].p, B, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t *out, int64_t B, int32_t with_keyswitch)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "bootstrap_batch: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "bootstrap_batch: context is multi-key");
+    if (!c->have_bk || (with_keyswitch && !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "bootstrap_batch: key not loaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = c->P.n, kNn = c->P.k * c->P.N;
+    const size_t in_bytes = (size_t)B * (n + 1) * 4;
+    HIP_TRY(c, c->io[0].reserve(in_bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->io[0].p, in, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->bara.reserve((size_t)B * (n + 1) * 4));
+    HIP_TRY(c, c->ext.reserve((size_t)B * (kNn + 1) * 4));
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(modswitch_kernel, dim3((unsigned)B), dim3(256), 0, s, (const int32_t *)c->io[0].p, (int32_t *)c->bara.p, n,
+                       ilog2i(2 * c->P.N));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    int32_t rc = launch_blind_rotate(c, (size_t)B, mu, s);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (with_keyswitch) {
+        // identity maps: e0[g] = g
+        rc = ensure_host_map(c, (size_t)B * 4);
+        if (rc) return rc;
+        for (int64_t g = 0; g < B; g++) ((int32_t *)c->h_map)[g] = (int32_t)g;
+        HIP_TRY(c, c->map.reserve((size_t)B * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, c->io[3].reserve(in_bytes));
+        rc = launch_keyswitch(c, (size_t)B, (const int32_t *)c->map.p, nullptr, nullptr, (const int32_t *)c->ext.p, (int32_t *)c->io[3].p, s);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, in_bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        HIP_TRY(c, hipMemcpyAsync(out, c->ext.p, (size_t)B * (kNn + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->timing_valid = true;
+    c->last_rotations = B;
+    return TFHE_OK;
+}
+
+int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64_t B)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "keyswitch_batch: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "keyswitch_batch: context is multi-key");
+    if (!c->have_ks) return c->set_err(TFHE_ERR_NO_KEY, "keyswitch_batch: keyswitch key not loaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = c->P.n, kNn = c->P.k * c->P.N;
+    const size_t in_bytes = (size_t)B * (kNn + 1) * 4, out_bytes = (size_t)B * (n + 1) * 4;
+    HIP_TRY(c, c->ext.reserve(in_bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->ext.p, in, in_bytes, hipMemcpyHostToDevice, s));
+    int32_t rc = ensure_host_map(c, (size_t)B * 4);
+    if (rc) return rc;
+    for (int64_t g = 0; g < B; g++) ((int32_t *)c->h_map)[g] = (int32_t)g;
+    HIP_TRY(c, c->map.reserve((size_t)B * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->io[3].reserve(out_bytes));
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    rc = launch_keyswitch(c, (size_t)B, (const int32_t *)c->map.p, nullptr, nullptr, (const int32_t *)c->ext.p, (int32_t *)c->io[3].p, s);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->timing_valid = true;
+    c->last_rotations = 0;
+    return TFHE_OK;
+}
+
+int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *, int32_t)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+}
+int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *, int32_t)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+}
+int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *, const int32_t *, int32_t *, int64_t)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+}
+
+int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
+{
+    if (!c || !ms) return TFHE_ERR_INVALID_ARG;
+    if (!c->timing_valid) return c->set_err(TFHE_ERR_STATE, "last_timing: no batch call recorded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev[3]));
+    int a, b;
+    switch (which) {
+    case 0: a = 1; b = 2; break;
+    case 1: a = 2; b = 3; break;
+    case 2: a = 0; b = 3; break;
+    default: return c->set_err(TFHE_ERR_INVALID_ARG, "last_timing: which must be 0, 1 or 2");
+    }
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return TFHE_OK;
+}
+
+int64_t tfhe_last_rotation_count(const tfhe_ctx *c) { return c ? c->last_rotations : -1; }
+
+int32_t tfhe_set_option(tfhe_ctx *c, const char *, int64_t)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    return TFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Keys, encryption, decryption on the host — mirrors src/api.jl:84-169 with the constructors of
+src/tlwe.jl:15-31, src/tgsw.jl:52-88, src/bootstrap.jl:1-16 and src/keyswitch.jl:7-42.
+
+Key material is generated once per key pair with numpy (RNG-bound host work, as in the reference);
+CloudKey keeps the flat arrays the C ABI takes (include/tfhe_mi355x.h) and uploads them to a
+device context on first use.  The random stream is numpy's (PCG64), not Julia's MersenneTwister:
+keys are data that crosses the boundary, the hot path itself consumes no randomness.
+"""
+import numpy as np
+
+from . import _lib
+from .lwe import LweKey, LweSample, LweSampleArray, lwe_encrypt, lwe_encrypt_many, lwe_phase
+from .numeric import (dtot32, encode_message, negacyclic_mul_binary, rand_gaussian_float,
+                      rand_uniform_bool, rand_uniform_torus32, wrap32)
+from .params import SchemeParameters, tfhe_parameters_80
+
+
+class TLweKey:
+    """tlwe.jl:11-21 — k binary polynomials."""
+
+    def __init__(self, rng, N, k):
+        self.N, self.k = N, k
+        self.key = rand_uniform_bool(rng, k, N)
+
+    def extract_lwe_key(self):
+        """tlwe.jl:25-31"""
+        return LweKey(None, self.k * self.N, key=self.key.reshape(-1))
+
+
+def _tlwe_encrypt_zero_many(rng, alpha, tlwe_key: TLweKey, count):
+    """`count` independent tlwe_encrypt_zero samples (tlwe.jl:63-73) -> int32 [count][k+1][N]."""
+    N, k = tlwe_key.N, tlwe_key.k
+    a_part = rand_uniform_torus32(rng, count, k, N)
+    noise = dtot32(rng.standard_normal(size=(count, N)) * alpha).astype(np.int64)
+    body = noise
+    for c in range(k):
+        body = body + negacyclic_mul_binary(tlwe_key.key[c], a_part[:, c, :]).astype(np.int64)
+    return np.concatenate([a_part, wrap32(body)[:, None, :]], axis=1)
+
+
+def make_bootstrap_key(rng, alpha, lwe_key: LweKey, tlwe_key: TLweKey, l, log2_base):
+    """BootstrapKey (bootstrap.jl:6-15) in the canonical Int32 form [n][l][k+1][k+1][N]:
+    key[i].samples[p, j].a[c], where samples = tgsw_encrypt(s_i) (tgsw.jl:84-88):
+    l*(k+1) zero encryptions plus s_i * 2^(32 - p*beta) on the constant term of component j of row (p, j)
+    (tgsw.jl:52-72; `Polynomial + scalar` adds to coefficient 0)."""
+    n, N, k = lwe_key.size, tlwe_key.N, tlwe_key.k
+    bk = _tlwe_encrypt_zero_many(rng, alpha, tlwe_key, n * l * (k + 1)).reshape(n, l, k + 1, k + 1, N)
+    s = lwe_key.key.astype(np.int64)
+    for p in range(l):
+        gadget = np.int64(1) << (32 - (p + 1) * log2_base)
+        for j in range(k + 1):
+            bk[:, p, j, j, 0] = wrap32(bk[:, p, j, j, 0].astype(np.int64) + s * gadget)
+    return np.ascontiguousarray(bk, np.int32)
+
+
+def make_keyswitch_key(rng, alpha, t, log2_base, out_key: LweKey, tlwe_key: TLweKey):
+    """KeyswitchKey (keyswitch.jl:14-41) as Int32 [kN][t][base-1][n+1] (= key[h, j, i] in Julia)."""
+    in_key = tlwe_key.extract_lwe_key()
+    kN, n = in_key.size, out_key.size
+    base = 1 << log2_base
+    noise = rand_gaussian_float(rng, alpha, kN, t, base - 1)
+    noise -= noise.sum() / noise.size                                        # keyswitch.jl:29
+    i = np.arange(kN)[:, None, None]
+    j = np.arange(1, t + 1)[None, :, None]
+    h = np.arange(1, base)[None, None, :]
+    message = (in_key.key.astype(np.int64)[i] * h) << (32 - j * log2_base)   # keyswitch.jl:35
+    a = rand_uniform_torus32(rng, kN, t, base - 1, n)
+    dot = (a.reshape(-1, n).astype(np.int64) @ out_key.key.astype(np.int64)).reshape(kN, t, base - 1)
+    b = wrap32(message + dtot32(noise).astype(np.int64) + dot)               # lwe.jl:49-55
+    return np.ascontiguousarray(np.concatenate([a, b[..., None]], axis=-1), np.int32)
+
+
+class SecretKey:
+    """api.jl:92-100"""
+
+    def __init__(self, rng, params: SchemeParameters):
+        self.params = params
+        self.key = LweKey(rng, params.lwe_size)
+
+
+class CloudKey:
+    """api.jl:111-127.  Holds the flat key arrays; `engine(device)` gives the device context."""
+
+    def __init__(self, rng, secret_key: SecretKey):
+        p = secret_key.params
+        self.params = p
+        tlwe_key = TLweKey(rng, p.tlwe_polynomial_degree, p.tlwe_mask_size)
+        self.bootstrap_key = make_bootstrap_key(rng, p.bs_noise_stddev, secret_key.key, tlwe_key,
+                                                p.bs_decomp_length, p.bs_log2_base)
+        self.keyswitch_key = make_keyswitch_key(rng, p.ks_noise_stddev, p.ks_decomp_length, p.ks_log2_base,
+                                                secret_key.key, tlwe_key)
+        self._engines = {}
+
+    def engine(self, device=0) -> "_lib.Engine":
+        e = self._engines.get(device)
+        if e is None:
+            e = _lib.Engine(self.params, device)
+            e.load_bootstrap_key(self.bootstrap_key)
+            e.load_keyswitch_key(self.keyswitch_key)
+            self._engines[device] = e
+        return e
+
+    def close(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+
+def make_key_pair(rng, params: SchemeParameters = None):
+    """api.jl:139-146"""
+    if params is None:
+        params = tfhe_parameters_80()
+    secret_key = SecretKey(rng, params)
+    cloud_key = CloudKey(rng, secret_key)
+    return secret_key, cloud_key
+
+
+def encrypt(rng, key: SecretKey, message):
+    """api.jl:155-158.  A bool gives an LweSample; an array of bools gives an LweSampleArray."""
+    alpha = key.params.lwe_noise_stddev
+    if np.ndim(message) == 0:
+        return lwe_encrypt(rng, encode_message(1 if message else -1, 8), alpha, key.key)
+    bits = np.asarray(message, bool).reshape(-1)
+    mu = np.where(bits, encode_message(1, 8), encode_message(-1, 8))
+    return LweSampleArray(lwe_encrypt_many(rng, mu, alpha, key.key))
+
+
+def decrypt(key: SecretKey, sample):
+    """api.jl:167-169 — phase > 0."""
+    if isinstance(sample, LweSample):
+        return bool(lwe_phase(sample.flat(), key.key) > 0)
+    data = sample.data if isinstance(sample, LweSampleArray) else np.asarray(sample, np.int32)
+    return lwe_phase(data, key.key) > 0
