@@ -1,0 +1,16 @@
+#!/bin/bash
+# Usage (on the GPU box, from the repo root): bash tools/profile.sh <tag> [bench args...]
+# Writes rocprofv3 kernel-trace stats and PMC passes under gpurun_out/prof_<tag>/.
+set -o pipefail
+TAG=${1:-run}; shift
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $ARGS > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -5 $OUT/stats.log; exit 1; }
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL"; do
+  NAME=$(echo $PMC | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc_$NAME -- python3 bench.py $ARGS > $OUT/pmc_$NAME.log 2>&1 || { echo "pmc pass $PMC failed"; tail -5 $OUT/pmc_$NAME.log; }
+done
+python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
