@@ -82,7 +82,43 @@ struct Tables {
     const cplx *tw1;    // [8][64]  e^{-2 pi i t q / 512}          (row 0 unused = 1)
     const cplx *tw2;    // [8][8]   e^{-2 pi i t' q2 / 64}
     const cplx *twist;  // [8][64]  e^{-i pi (t + 64 r) / N}       polynomials.jl:53
+    const cplx *tw1f;   // [8][64]  e^{-i pi t / N} * e^{-2 pi i t q / 512}   (tw1 with the lane part of the twist folded in)
 };
+constexpr int kTableElems = 512 + 64 + 512 + 512;
+
+// Fills a host array of kTableElems cplx: tw1 | tw2 | twist | tw1f (long-double sincos).
+template <typename LD, typename COS, typename SIN>
+inline void fill_tables(cplx *h, COS cosfn, SIN sinfn)
+{
+    const LD pi = (LD)3.14159265358979323846264338327950288L;
+    for (int q = 0; q < 8; q++)
+        for (int t = 0; t < 64; t++) {
+            const LD a = (LD)-2 * pi * (LD)(t * q) / (LD)512;
+            h[q * 64 + t].x = (double)cosfn(a); h[q * 64 + t].y = (double)sinfn(a);
+        }
+    for (int q = 0; q < 8; q++)
+        for (int t = 0; t < 8; t++) {
+            const LD a = (LD)-2 * pi * (LD)(t * q) / (LD)64;
+            h[512 + q * 8 + t].x = (double)cosfn(a); h[512 + q * 8 + t].y = (double)sinfn(a);
+        }
+    for (int r = 0; r < 8; r++)
+        for (int t = 0; t < 64; t++) {
+            const LD a = -pi * (LD)(t + 64 * r) / (LD)kN;
+            h[576 + r * 64 + t].x = (double)cosfn(a); h[576 + r * 64 + t].y = (double)sinfn(a);
+        }
+    for (int q = 0; q < 8; q++)
+        for (int t = 0; t < 64; t++) {
+            // e^{-i pi t/N} * e^{-2 pi i t q/512} = e^{-i pi t (1 + 4 q) / N}   (N = 1024)
+            const LD a = -pi * (LD)(t * (1 + 4 * q)) / (LD)kN;
+            h[1088 + q * 64 + t].x = (double)cosfn(a); h[1088 + q * 64 + t].y = (double)sinfn(a);
+        }
+}
+inline Tables tables_from(const cplx *base)
+{
+    Tables T;
+    T.tw1 = base; T.tw2 = base + 512; T.twist = base + 576; T.tw1f = base + 1088;
+    return T;
+}
 
 // ---- LDS exchange addressing (units of cplx) ---------------------------------------------------
 // exchange 1: [q][t] rows of 64 padded to 72; exchange 2: transposes inside 8-lane groups.
@@ -249,5 +285,110 @@ TFHE_HD void untwist_add(int lane, const cplx (&y)[8], const Tables &T, int32_t 
 
 // Frequency index held by (lane, reg) after the forward transform.
 TFHE_HD int freq_of(int lane, int k2) { return (lane >> 3) + 8 * (lane & 7) + 64 * k2; }
+
+// =================================================================================================
+// v2 lane code: twiddles resident in registers, the twist split into a lane part (folded into the
+// pass-A twiddles, tw1f) and a register part c_r = e^{-i pi r/16} (compile-time constants), digits by
+// signed bit-field extract.  Same transform as above up to rounding.
+// =================================================================================================
+struct LaneTw {
+    cplx tw1f[8];   // [q]  e^{-i pi t/N} e^{-2 pi i t q/512}
+    cplx tw2[8];    // [q2] e^{-2 pi i t' q2/64}, t' = lane & 7 ([0] unused)
+};
+TFHE_HD void load_lane_tw(int lane, const Tables &T, LaneTw &w)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        w.tw1f[q] = T.tw1f[q * 64 + lane];
+        w.tw2[q] = T.tw2[q * 8 + (lane & 7)];
+    }
+}
+// cos(pi r/16), sin(pi r/16)
+TFHE_HD constexpr double twc(int r)
+{
+    return r == 0 ? 1.0 : r == 1 ? 0.98078528040323044913 : r == 2 ? 0.92387953251128675613
+         : r == 3 ? 0.83146961230254523708 : r == 4 ? 0.70710678118654752440 : r == 5 ? 0.55557023301960222474
+         : r == 6 ? 0.38268343236508977173 : 0.19509032201612826785;
+}
+TFHE_HD constexpr double tws(int r)
+{
+    return r == 0 ? 0.0 : r == 1 ? 0.19509032201612826785 : r == 2 ? 0.38268343236508977173
+         : r == 3 ? 0.55557023301960222474 : r == 4 ? 0.70710678118654752440 : r == 5 ? 0.83146961230254523708
+         : r == 6 ? 0.92387953251128675613 : 0.98078528040323044913;
+}
+
+// xor mask that turns every beta-bit digit field into its signed (two's complement) form
+TFHE_HD int32_t gadget_xor_mask(int l, int log2_base)
+{
+    uint32_t m = 0;
+    for (int p = 1; p <= l; p++) m |= 1u << (32 - p * log2_base + log2_base - 1);
+    return (int32_t)m;
+}
+// temp[m] = ((X^a - 1) acc + offset) ^ xormask for this lane's 16 coefficients
+TFHE_HD void rotate_sub2(int lane, int a_mod_2N, const int32_t *acc_lds, const int32_t (&cur)[16],
+                         int32_t offset, int32_t xormask, int32_t (&temp)[16])
+{
+    const int base = (lane - a_mod_2N) & (2 * kN - 1);
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int idx = (base + 64 * m) & (2 * kN - 1);
+        const int32_t v = acc_lds[idx & (kN - 1)];
+        const uint32_t sgn = (idx & kN) ? 0xFFFFFFFFu : 0u;
+        const uint32_t r = ((uint32_t)v ^ sgn) - sgn;
+        temp[m] = (int32_t)((r - (uint32_t)cur[m] + (uint32_t)offset) ^ (uint32_t)xormask);
+    }
+}
+// digit p (1-based) of a prepared coefficient: signed bit-field extract
+TFHE_HD int32_t digit2(int32_t t, int p, int log2_base)
+{
+    return (int32_t)((uint32_t)t << ((p - 1) * log2_base)) >> (32 - log2_base);
+}
+// x[r] = (d[t+64r] - i d[t+64r+512]) * e^{-i pi r/16}
+TFHE_HD void load_digits2(const int32_t (&temp)[16], int p, int log2_base, cplx (&x)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double lo = (double)digit2(temp[r], p, log2_base);
+        const double hi = (double)digit2(temp[r + 8], p, log2_base);
+        if (r == 0) x[r] = mk(lo, -hi);
+        else x[r] = mk(lo * twc(r) - hi * tws(r), -(lo * tws(r) + hi * twc(r)));
+    }
+}
+TFHE_HD void fwd2_pass_a(cplx (&x)[8], const LaneTw &w)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], w.tw1f[q]);
+}
+TFHE_HD void fwd2_pass_b(cplx (&x)[8], const LaneTw &w)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], w.tw2[q]);
+}
+TFHE_HD void inv2_pass_b(cplx (&x)[8], const LaneTw &w)
+{
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], w.tw2[q]);
+    dft8<true>(x);
+}
+TFHE_HD void inv2_pass_a(cplx (&x)[8], const LaneTw &w)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], w.tw1f[q]);
+    dft8<true>(x);
+}
+// conj(y) * e^{-i pi r/16}: real -> coefficient t+64r, imag -> t+64r+512; round, add into acc
+TFHE_HD void untwist_add2(const cplx (&y)[8], int32_t (&acc)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        double re, im;
+        if (r == 0) { re = y[r].x; im = -y[r].y; }
+        else { re = y[r].x * twc(r) - y[r].y * tws(r); im = -(y[r].x * tws(r) + y[r].y * twc(r)); }
+        acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
+        acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(im));
+    }
+}
 
 }  // namespace tfhe

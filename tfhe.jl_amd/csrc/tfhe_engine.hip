@@ -207,6 +207,175 @@ __global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
     if (lane == 0) ext[(K1 - 1) * kN] = acc[K1 - 1][0];
 }
 
+// Wave-private LDS hand-off: LDS instructions of one wave execute in issue order, so a compiler-level
+// fence is all a single-wave workgroup needs between a ds_write and the ds_read of another lane's data.
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+// v3: one wave per blind rotation at 2 waves/SIMD (<= 256 VGPRs, no AGPR/scratch spills).
+//   * pass-A twiddles (with the lane part of the twist folded in) resident in registers, pass-B twiddles
+//     in a 1 KB wave-private LDS table, the register part of the twist as compile-time constants:
+//     no global loads on the critical path except the key;
+//   * the accumulator lives only in LDS (read at rotate time and at the final add);
+//   * key spectra of the next transform prefetched into registers while the current FFT runs;
+//   * no s_barrier: wave-private LDS needs only compiler-level ordering;
+//   * no branch on bara[i] == 0 (the step then adds exactly zero).
+template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */>
+__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
+{
+    constexpr int K1 = 2;
+    constexpr int F = K1 * L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [kXchElems]
+    cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+
+    cplx kbuf[16];
+    // chunk f of step: key spectra for transform f = (c, p): 16 values per lane (co-major, k2 minor)
+    auto key_ptr = [&](int step, int f) {
+        const int c = f / L, p = f % L;
+        return P.bk + (size_t)step * (L * K1 * K1 * kM) + (size_t)(p * K1 + c) * K1 * kM + lane;
+    };
+    {
+        const cplx *kp = key_ptr(0, 0);
+#pragma unroll
+        for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
+    }
+
+    int a_next = bara[0] & (2 * kN - 1);
+    for (int i = 0; i < P.n; i++) {
+        const int a = a_next;
+        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+
+        cplx out[K1][8];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
+
+        int32_t temp[16];
+#pragma unroll 1
+        for (int f = 0; f < F; f++) {
+            const int c = f / L, p = f % L;        // component, digit index (0-based)
+            if (p == 0) {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));   // keeps the 32 rotate addresses/signs from being hoisted out of the f loop
+                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
+            }
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            // pass A
+            dft8<false>(x);
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+            x1_store_a(lane, x, xch);
+            WAVE_LDS_FENCE();
+            x1_load_b(lane, x, xch);
+            // pass B (twiddles from the LDS table)
+            {
+                cplx t2[8];
+#pragma unroll
+                for (int q = 1; q < 8; q++) t2[q] = tw2_lds[q * 8 + (lane & 7)];
+                dft8<false>(x);
+#pragma unroll
+                for (int q = 1; q < 8; q++) x[q] = cmul(x[q], t2[q]);
+            }
+            WAVE_LDS_FENCE();
+            x2_store(lane, x, xch);
+            WAVE_LDS_FENCE();
+            x2_load(lane, x, xch);
+            WAVE_LDS_FENCE();
+            dft8<false>(x);
+            // MAC: out[co] += D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128)
+            if (KPF == 16) {
+#pragma unroll
+                for (int co = 0; co < K1; co++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
+            } else {
+                const cplx *kp = key_ptr(i, f);
+                cplx k1v[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kbuf[k2], out[0][k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], k1v[k2], out[1][k2]);
+            }
+            // prefetch the next transform's key
+            {
+                const bool last = (f + 1 == F);
+                // (unconditional: on the very last transform this re-reads a valid chunk; a conditional
+                //  prefetch doubles the register pressure through the phi of old and new values)
+                const cplx *kp = last ? key_ptr(i + 1 < P.n ? i + 1 : i, 0) : key_ptr(i, f + 1);
+#pragma unroll
+                for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < K1; co++) {
+            dft8<true>(out[co]);
+            x2_store(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+            x2_load(lane, out[co], xch);
+            {
+                cplx t2[8];
+#pragma unroll
+                for (int q = 1; q < 8; q++) t2[q] = tw2_lds[q * 8 + (lane & 7)];
+#pragma unroll
+                for (int q = 1; q < 8; q++) out[co][q] = cmulc(out[co][q], t2[q]);
+            }
+            dft8<true>(out[co]);
+            WAVE_LDS_FENCE();
+            x1_store_b(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+            x1_load_a(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[co][q] = cmulc(out[co][q], tw1f[q]);
+            dft8<true>(out[co]);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + lane + 64 * m];
+            untwist_add2(out[co], accr);
+            store_acc<K1>(lane, accr, acc_lds + co * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+
+    int32_t *ext = P.ext + w * (kN + 1);
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int j = lane + 64 * m;
+        const int32_t v = acc_lds[j];
+        if (j == 0) ext[0] = v;
+        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (lane == 0) ext[kN] = acc_lds[kN];
+}
+
 // Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
 // (the analogue of forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
@@ -352,6 +521,7 @@ struct tfhe_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
     bool timing_valid = false;
     int64_t last_rotations = 0;
+    int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
     // tables
     cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
@@ -389,24 +559,8 @@ struct tfhe_ctx {
 
 static void build_tables(std::vector<cplx> &h)
 {
-    // tw1[q][t] = e^{-2 pi i t q/512}; tw2[q][t'] = e^{-2 pi i t' q/64}; twist[r][t] = e^{-i pi (t+64r)/N}
-    const long double pi = 3.14159265358979323846264338327950288L;
-    h.resize(512 + 64 + 512);
-    for (int q = 0; q < 8; q++)
-        for (int t = 0; t < 64; t++) {
-            const long double a = -2.0L * pi * (long double)(t * q) / 512.0L;
-            h[q * 64 + t] = mk((double)cosl(a), (double)sinl(a));
-        }
-    for (int q = 0; q < 8; q++)
-        for (int t = 0; t < 8; t++) {
-            const long double a = -2.0L * pi * (long double)(t * q) / 64.0L;
-            h[512 + q * 8 + t] = mk((double)cosl(a), (double)sinl(a));
-        }
-    for (int r = 0; r < 8; r++)
-        for (int t = 0; t < 64; t++) {
-            const long double a = -pi * (long double)(t + 64 * r) / (long double)kN;
-            h[576 + r * 64 + t] = mk((double)cosl(a), (double)sinl(a));
-        }
+    h.resize(kTableElems);
+    fill_tables<long double>(h.data(), [](long double a) { return cosl(a); }, [](long double a) { return sinl(a); });
 }
 
 static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
@@ -472,9 +626,7 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
     if ((e = hipMalloc((void **)&c->d_tables, h.size() * sizeof(cplx))) != hipSuccess) return bail(e, "hipMalloc(tables)");
     if ((e = hipMemcpy(c->d_tables, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(e, "hipMemcpy(tables)");
-    c->T.tw1 = c->d_tables;
-    c->T.tw2 = c->d_tables + 512;
-    c->T.twist = c->d_tables + 576;
+    c->T = tables_from(c->d_tables);
     *out_ctx = c;
     return TFHE_OK;
 }
@@ -574,6 +726,21 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.g = c->g;
     a.n = c->P.n;
     a.mu = mu;
+    if (c->br_variant >= 2) {
+        const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+#define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK>), dim3((unsigned)R), dim3(64), lds3, s, a)
+        const bool half = (c->br_variant == 3);
+        switch (c->P.bs_l) {
+        case 1: if (half) LAUNCH_V3(1, 8); else LAUNCH_V3(1, 16); break;
+        case 2: if (half) LAUNCH_V3(2, 8); else LAUNCH_V3(2, 16); break;
+        case 3: if (half) LAUNCH_V3(3, 8); else LAUNCH_V3(3, 16); break;
+        case 4: if (half) LAUNCH_V3(4, 8); else LAUNCH_V3(4, 16); break;
+        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+        }
+#undef LAUNCH_V3
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
     const size_t lds = 2 * kN * 4 + kXchElems * sizeof(cplx);
     switch (c->P.bs_l) {
     case 1: hipLaunchKernelGGL((blind_rotate_kernel<1, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
@@ -841,10 +1008,16 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
 
 int64_t tfhe_last_rotation_count(const tfhe_ctx *c) { return c ? c->last_rotations : -1; }
 
-int32_t tfhe_set_option(tfhe_ctx *c, const char *, int64_t)
+int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return TFHE_OK;
+    if (!name || !*name) return TFHE_OK;
+    if (!strcmp(name, "br_variant")) {
+        if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 1, 2 or 3");
+        c->br_variant = (int)value;
+        return TFHE_OK;
+    }
+    return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: unknown option '%s'", name);
 }
 
 }  // extern "C"
