@@ -475,6 +475,218 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
     }
 }
 
+// keyswitch v2: a workgroup owns G output samples and every output word (thread t -> word t), so each
+// keyswitch-key row is fetched once per G samples instead of once per sample (the v1 kernel moves
+// B * 6144 rows * 2 KB through L2; this one B/G * 24576 rows).  The digits of a sample are wave-uniform:
+// the rounded mask words sit in LDS, are read as a broadcast and moved to SGPRs with readfirstlane, and
+// the row to subtract is selected with scalar masks (no divergent branches, no row for digit 0 -
+// keyswitch.jl:32-38,73-75).
+template <int G, int IB /* mask words staged in LDS per block */>
+__global__ __launch_bounds__(512) void keyswitch_kernel_v2(KsArgs P, int B)
+{
+    __shared__ int32_t abar[G][IB];
+    const int tid = threadIdx.x;
+    const int n1 = P.n + 1;
+    const int g0 = blockIdx.x * G;
+    const int t_len = P.t, lb = P.log2_base;
+    const int base1 = (1 << lb) - 1;
+    const uint32_t prec_offset = 1u << (32 - (1 + lb * t_len));             // keyswitch.jl:58
+    const bool active = tid < n1;
+    const int wd = active ? tid : 0;
+
+    uint32_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = 0;
+
+    for (int i0 = 0; i0 < P.kN; i0 += IB) {
+        __syncthreads();
+        // stage aibar = a_i + prec_offset for G samples x IB mask words (MUX: sum of two extracted samples)
+        for (int idx = tid; idx < G * IB; idx += 512) {
+            const int g = idx / IB, ii = idx % IB;
+            const int gg = min(g0 + g, B - 1);
+            const int i = i0 + ii;
+            uint32_t ai = 0;
+            if (i < P.kN) {
+                ai = (uint32_t)P.ext[(size_t)P.e0[gg] * (P.kN + 1) + i];
+                const int e1 = P.e1 ? P.e1[gg] : -1;
+                if (e1 >= 0) ai += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + i];
+                ai += prec_offset;                                           // keyswitch.jl:59
+            } else {
+                ai = 0;   // digits all zero: contributes nothing
+            }
+            abar[g][ii] = (int32_t)ai;
+        }
+        __syncthreads();
+        const int iend = min(IB, P.kN - i0);
+        for (int ii = 0; ii < iend; ii++) {
+            const int32_t *rows_i = P.ks + (size_t)(i0 + ii) * t_len * base1 * n1 + wd;
+            for (int j = 0; j < t_len; j++) {
+                // the (base-1) candidate rows for digit position j; base = 4 in every shipped set,
+                // general base handled by the loop over h
+                const int32_t *rj = rows_i + (size_t)j * base1 * n1;
+                const int sh = 32 - (j + 1) * lb;
+                if (base1 == 3) {
+                    const uint32_t r1 = (uint32_t)rj[0], r2 = (uint32_t)rj[n1], r3 = (uint32_t)rj[2 * n1];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const int a = __builtin_amdgcn_readfirstlane(abar[g][ii]);
+                        const int d = (a >> sh) & 3;                         // keyswitch.jl:65-67
+                        const uint32_t m1 = d == 1 ? 0xFFFFFFFFu : 0u, m2 = d == 2 ? 0xFFFFFFFFu : 0u,
+                                       m3 = d == 3 ? 0xFFFFFFFFu : 0u;
+                        acc[g] -= (r1 & m1) | (r2 & m2) | (r3 & m3);         // keyswitch.jl:73-75
+                    }
+                } else {
+                    for (int h = 1; h <= base1; h++) {
+                        const uint32_t r = (uint32_t)rj[(size_t)(h - 1) * n1];
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            const int a = __builtin_amdgcn_readfirstlane(abar[g][ii]);
+                            const int d = (a >> sh) & base1;
+                            acc[g] -= (d == h) ? r : 0u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int gg = g0 + g;
+        if (gg >= B) break;
+        uint32_t v = acc[g];
+        if (tid == P.n) {                                                    // keyswitch.jl:50
+            v += (uint32_t)P.ext[(size_t)P.e0[gg] * (P.kN + 1) + P.kN];
+            const int e1 = P.e1 ? P.e1[gg] : -1;
+            if (e1 >= 0) v += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + P.kN] + (1u << 29);   // gates.jl:174
+        }
+        const size_t og = P.dst ? (size_t)P.dst[gg] : (size_t)gg;
+        P.out[og * n1 + tid] = (int32_t)v;
+    }
+}
+
+// ---- keyswitch v3 ---------------------------------------------------------------------------------
+// Work decomposition: (tile of KS3_G samples) x (slice of kN/KS3_SLICES mask words) x (chunk of 512
+// output words).  A lane owns 4 consecutive output words (16-byte loads from the row-padded key), a
+// wave-uniform digit selects among the three candidate rows with two scalar bit-masks (s_bfe_i32) and
+// four vector ops per word, and the slices' partial sums are combined with integer atomics (exact and
+// order-independent).  Blocks are numbered so that blocks sharing a slice share an XCD: each XCD's L2
+// then holds only its own 1/8 of the key, which is fetched from beyond L2 once.
+constexpr int KS3_G = 16;        // samples per block
+constexpr int KS3_SLICES = 16;   // slices of the kN mask words (multiple of 8)
+
+struct Ks3Args {
+    const int32_t *ext;     // [R][kN+1]
+    const int32_t *ksp;     // [kN][t][base-1][stride]  rows padded to a multiple of 4 words
+    const int32_t *e0, *e1, *dst;
+    int32_t *out;           // [B][n+1], pre-initialised to (0, ..., 0, b) by ks3_init_kernel
+    int32_t n, kN, t, log2_base, stride, G;
+};
+
+__global__ void ks3_init_kernel(Ks3Args P)
+{
+    const int g = blockIdx.x;
+    const size_t og = P.dst ? (size_t)P.dst[g] : (size_t)g;
+    int32_t *o = P.out + og * (P.n + 1);
+    for (int w = threadIdx.x; w < P.n; w += blockDim.x) o[w] = 0;
+    if (threadIdx.x == 0) {
+        uint32_t b = (uint32_t)P.ext[(size_t)P.e0[g] * (P.kN + 1) + P.kN];               // keyswitch.jl:50
+        const int e1 = P.e1 ? P.e1[g] : -1;
+        if (e1 >= 0) b += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + P.kN] + (1u << 29);  // gates.jl:174
+        o[P.n] = (int32_t)b;
+    }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
+{
+    constexpr int G = KS3_G;
+    constexpr int JH = 4;                         // digit positions per pipeline stage
+    __shared__ int32_t abar[G][128];              // slice length <= 128
+    const int tid = threadIdx.x;
+    // XCD-aware numbering: consecutive block ids go round-robin over the 8 XCDs
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7;
+    const int rest = lin >> 3;
+    const int slice = xcd + 8 * (rest % (KS3_SLICES / 8));
+    const int tile = rest / (KS3_SLICES / 8);
+    const int wchunk = blockIdx.y;                // 512-word chunk of the output
+    const int g0 = tile * G;
+    const int slen = P.kN / KS3_SLICES;
+    const int i0 = slice * slen;
+    const int lb = P.log2_base, tl = P.t;
+    const int base1 = (1 << lb) - 1;              // == 3 (checked by the launcher)
+    const uint32_t prec_offset = 1u << (32 - (1 + lb * tl));                 // keyswitch.jl:58
+    const int w0 = wchunk * 512 + tid * 4;        // first of this lane's 4 words
+    const bool active = w0 < P.stride;
+    const int wl = active ? w0 : 0;
+
+    for (int idx = tid; idx < G * slen; idx += 128) {
+        const int g = idx / slen, ii = idx % slen;
+        const int gg = min(g0 + g, P.G - 1);
+        uint32_t ai = (uint32_t)P.ext[(size_t)P.e0[gg] * (P.kN + 1) + i0 + ii];
+        const int e1 = P.e1 ? P.e1[gg] : -1;
+        if (e1 >= 0) ai += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + i0 + ii];
+        abar[g][ii] = (int32_t)(ai + prec_offset);                           // keyswitch.jl:59
+    }
+    __syncthreads();
+
+    u32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = (u32x4)(0u);
+
+    const size_t row_words = (size_t)P.stride;
+    const int stages = slen * (tl / JH);          // tl is a multiple of JH (checked by the launcher)
+    auto load_stage = [&](int st, u32x4 (&r)[JH][3]) {
+        const int ii = st / (tl / JH), jh = st % (tl / JH);
+        const int32_t *rows = P.ksp + ((size_t)(i0 + ii) * tl + jh * JH) * base1 * row_words + wl;
+#pragma unroll
+        for (int j = 0; j < JH; j++)
+#pragma unroll
+            for (int h = 0; h < 3; h++) r[j][h] = *reinterpret_cast<const u32x4 *>(rows + (size_t)(j * 3 + h) * row_words);
+    };
+    auto compute_stage = [&](int st, const u32x4 (&r)[JH][3]) {
+        const int ii = st / (tl / JH), jh = st % (tl / JH);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int a = __builtin_amdgcn_readfirstlane(abar[g][ii]);
+#pragma unroll
+            for (int j = 0; j < JH; j++) {
+                const int pos = 32 - (jh * JH + j + 1) * lb;                 // digit = bits [pos, pos+1]  keyswitch.jl:65-67
+                const uint32_t m0 = (uint32_t)((a << (31 - pos)) >> 31);     // -(bit 0 of the digit)
+                const uint32_t m1 = (uint32_t)((a << (30 - pos)) >> 31);     // -(bit 1 of the digit)
+                // digit 0 -> 0, 1 -> r1, 2 -> r2, 3 -> r3                    keyswitch.jl:73-75
+                const u32x4 t = (r[j][2] & m1) | (r[j][0] & ~m1);
+                const u32x4 u = r[j][1] & m1;
+                acc[g] -= (t & m0) | (u & ~m0);
+            }
+        }
+    };
+
+    u32x4 ra[JH][3], rb[JH][3];
+    load_stage(0, ra);
+    for (int st = 0; st < stages; st += 2) {
+        if (st + 1 < stages) load_stage(st + 1, rb);
+        compute_stage(st, ra);
+        if (st + 2 < stages) load_stage(st + 2, ra);
+        if (st + 1 < stages) compute_stage(st + 1, rb);
+    }
+
+    if (!active) return;
+    const int n1 = P.n + 1;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int gg = g0 + g;
+        if (gg >= P.G) break;
+        const size_t og = P.dst ? (size_t)P.dst[gg] : (size_t)gg;
+        int32_t *o = P.out + og * n1;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (w0 + q < n1) atomicAdd(reinterpret_cast<unsigned int *>(o + w0 + q), acc[g][q]);
+    }
+}
+
 // gate_not / gate_constant / copy (gates.jl:76-93)
 __global__ void trivial_gates_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ gates,
                                      const uint8_t *__restrict__ ops, int32_t *__restrict__ out, int n)
@@ -521,6 +733,7 @@ struct tfhe_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
     bool timing_valid = false;
     int64_t last_rotations = 0;
+    int ks_variant = 3;          // 1 = one workgroup per sample, 2 = gate-tiled, 3 = tiled + sliced + XCD-aware (default)
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
     // tables
@@ -531,6 +744,7 @@ struct tfhe_ctx {
     // keys
     cplx *d_bk = nullptr;       size_t bk_polys = 0;
     int32_t *d_ks = nullptr;
+    int32_t *d_ksp = nullptr;   int ks_stride = 0;   // row-padded copy for keyswitch_kernel_v3
     bool have_bk = false, have_ks = false;
 
     // workspaces
@@ -639,6 +853,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_ks) (void)hipFree(c->d_ks);
+    if (c->d_ksp) (void)hipFree(c->d_ksp);
     c->bara.release(); c->ext.release(); c->map.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
@@ -711,6 +926,15 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; c->have_ks = false; }
     HIP_TRY(c, hipMalloc((void **)&c->d_ks, bytes));
     HIP_TRY(c, hipMemcpy(c->d_ks, ks, bytes, hipMemcpyHostToDevice));
+    {   // row-padded copy: stride = n+1 rounded up to 4 words so that rows are 16-byte aligned
+        const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
+        const size_t rows = ks_word_count(c->P) / n1;
+        if (c->d_ksp) { (void)hipFree(c->d_ksp); c->d_ksp = nullptr; }
+        HIP_TRY(c, hipMalloc((void **)&c->d_ksp, rows * stride * 4));
+        HIP_TRY(c, hipMemset(c->d_ksp, 0, rows * stride * 4));
+        HIP_TRY(c, hipMemcpy2D(c->d_ksp, stride * 4, c->d_ks, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice));
+        c->ks_stride = (int)stride;
+    }
     c->have_ks = true;
     return TFHE_OK;
 }
@@ -763,6 +987,23 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     k.out = out;
     k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
     const int n1 = c->P.n + 1;
+    if (c->ks_variant == 3 && c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && k.kN % (KS3_SLICES * 1) == 0 &&
+        k.kN / KS3_SLICES <= 128) {
+        Ks3Args a3;
+        a3.ext = ext; a3.ksp = c->d_ksp; a3.e0 = e0; a3.e1 = e1; a3.dst = dst; a3.out = out;
+        a3.n = c->P.n; a3.kN = k.kN; a3.t = c->P.ks_t; a3.log2_base = 2; a3.stride = c->ks_stride; a3.G = (int)G;
+        hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)G), dim3(256), 0, s, a3);
+        const unsigned tiles = (unsigned)((G + KS3_G - 1) / KS3_G);
+        hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, a3);
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
+    if (c->ks_variant == 2 && n1 <= 512) {
+        constexpr int KG = 16;
+        hipLaunchKernelGGL((keyswitch_kernel_v2<KG, 128>), dim3((unsigned)((G + KG - 1) / KG)), dim3(512), 0, s, k, (int)G);
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
     if (n1 <= 256) hipLaunchKernelGGL((keyswitch_kernel<1>), dim3((unsigned)G), dim3(256), 0, s, k);
     else if (n1 <= 512) hipLaunchKernelGGL((keyswitch_kernel<2>), dim3((unsigned)G), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((keyswitch_kernel<4>), dim3((unsigned)G), dim3(256), 0, s, k);
@@ -1015,6 +1256,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "br_variant")) {
         if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 1, 2 or 3");
         c->br_variant = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "ks_variant")) {
+        if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 2 or 3");
+        c->ks_variant = (int)value;
         return TFHE_OK;
     }
     return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: unknown option '%s'", name);
