@@ -109,8 +109,8 @@ int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
 int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk);
 
 /* BootstrapKey from the reference's stored spectra, complex128 [n][l][k+1][k+1][N/2] as produced by
- * polynomials.jl:106-112; the engine applies the reference's inverse_transform (polynomials.jl:119-132,
- * exact: values are integers) on the device and proceeds as above. */
+ * polynomials.jl:106-112.  The engine's spectrum domain is the reference's (same fold, twist and
+ * transform sign), so loading is a permutation into the engine's order plus the 1/M scaling. */
 int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra);
 
 /* KeyswitchKey (keyswitch.jl:7-42), Int32 [kN][t][base-1][n+1]. */
