@@ -1,0 +1,78 @@
+"""Multi-key (2-party) NAND — BASELINE config 5, reference test "multikey NAND" (test/runtests.jl:60-100).
+CPU: the oracle's MK restatement decrypts correctly under the host MK key generator and its two product
+back-ends agree.  GPU: the HIP path equals the oracle word for word (decrypt-level MK tests are inherently
+~0.2 %/gate flaky — SURVEY §4 — so parity is asserted on ciphertext words)."""
+import numpy as np
+import pytest
+
+
+class MKKeys:
+    def __init__(self, tfhe, orc, n=None, seed=321):
+        p = tfhe.mktfhe_parameters_2party
+        if n is not None:   # reduced lwe_size for fast CPU tests; everything else as mk_api.jl:4-10
+            p = tfhe.SchemeParameters(n, p.lwe_noise_stddev, 1024, 1, p.bs_decomp_length, p.bs_log2_base,
+                                      p.bs_noise_stddev, p.ks_decomp_length, p.ks_log2_base, p.ks_noise_stddev, 2)
+        self.params = p
+        self.rng = np.random.default_rng(seed)
+        self.sks = [tfhe.SecretKey(self.rng, p) for _ in range(2)]                  # runtests.jl:69
+        shared = tfhe.SharedKey(self.rng, p)                                        # :72
+        parts = [tfhe.CloudKeyPart(self.rng, sk, shared) for sk in self.sks]        # :75
+        self.ck = tfhe.MKCloudKey(parts)                                            # :79
+        self.oracle = orc.Oracle(p.lwe_size, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length,
+                                 p.ks_log2_base, parties=2)
+        self.oracle.load_bootstrap_key(self.ck.bootstrap_key)
+        self.oracle.load_keyswitch_key(self.ck.keyswitch_key)
+
+
+@pytest.fixture(scope="module")
+def mk_small(tfhe, orc):
+    return MKKeys(tfhe, orc, n=24)
+
+
+@pytest.fixture(scope="module")
+def mk_full(tfhe, orc):
+    return MKKeys(tfhe, orc)
+
+
+def test_mk_encrypt_decrypt_roundtrip(tfhe, mk_small):
+    K = mk_small
+    bits = K.rng.integers(0, 2, 32).astype(bool)
+    assert np.array_equal(tfhe.mk_decrypt(K.sks, tfhe.mk_encrypt(K.rng, K.sks, bits)), bits)   # runtests.jl:90-93
+    assert tfhe.mk_decrypt(K.sks, tfhe.mk_encrypt(K.rng, K.sks, True)) is True
+
+
+def test_mk_oracle_backends_agree(orc, tfhe, mk_small):
+    K = mk_small
+    x = tfhe.mk_encrypt(K.rng, K.sks, [True, False])
+    y = tfhe.mk_encrypt(K.rng, K.sks, [True, True])
+    a = K.oracle.mk_gate_nand(x, y, mode=orc.MODE_FFT)
+    assert K.oracle.last_margin < 0.25
+    assert np.array_equal(a, K.oracle.mk_gate_nand(x, y, mode=orc.MODE_EXACT))
+
+
+def test_mk_oracle_nand_decrypts(orc, tfhe, mk_full):
+    """test/runtests.jl:82-99 on the oracle: 10 random trials."""
+    K = mk_full
+    m1, m2 = K.rng.integers(0, 2, 10).astype(bool), K.rng.integers(0, 2, 10).astype(bool)
+    out = K.oracle.mk_gate_nand(tfhe.mk_encrypt(K.rng, K.sks, m1), tfhe.mk_encrypt(K.rng, K.sks, m2), nthreads=8)
+    ok = tfhe.mk_decrypt(K.sks, out) == ~(m1 & m2)
+    assert ok.sum() >= 9      # ~3 sigma margin per gate: allow one noise failure in ten
+
+
+@pytest.mark.gpu
+def test_mk_gpu_parity(orc, tfhe, mk_full):
+    K = mk_full
+    B = 24
+    m1, m2 = K.rng.integers(0, 2, B).astype(bool), K.rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.mk_encrypt(K.rng, K.sks, m1), tfhe.mk_encrypt(K.rng, K.sks, m2)
+    got = tfhe.mk_gate_nand(K.ck, x, y)
+    want = K.oracle.mk_gate_nand(x, y, nthreads=8)
+    assert np.array_equal(got, want)
+    assert (tfhe.mk_decrypt(K.sks, got) == ~(m1 & m2)).sum() >= B - 2
+    # arbitrary input words (mod-switch edges) and a single sample
+    z = K.rng.integers(-2**31, 2**31, size=(3, 1001), dtype=np.int64).astype(np.int32)
+    z[0, :4] = [2**31 - 1, -2**31, 2**20, 0]
+    assert np.array_equal(tfhe.mk_gate_nand(K.ck, z, z[::-1].copy()), K.oracle.mk_gate_nand(z, z[::-1].copy(), nthreads=4))
+    one = tfhe.mk_gate_nand(K.ck, x[0], y[0])
+    assert one.shape == (1001,) and np.array_equal(one, want[0])
+    K.ck.close()

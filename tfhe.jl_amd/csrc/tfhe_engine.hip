@@ -376,6 +376,179 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     if (lane == 0) ext[kN] = acc_lds[kN];
 }
 
+// ---- multi-key blind rotation (2 parties) ----------------------------------------------------------
+// mk_internals.jl:464-495 (mk_mux_rotate, mk_blind_rotate, extract) with mk_tgsw_extern_mul (:348-391).
+// Accumulator = P mask polynomials + body (P = 2): 3 polynomials in LDS.  Per step (party i, bit j):
+// 3*L forward transforms, MAC against the expanded key polys x, y, c0, c1 of (i, j), 3 inverse
+// transforms.  The reference inverse-transforms every product separately and sums in Int32
+// (:359-366); summing in the spectrum domain first gives the same words (both are the exact product
+// mod 2^32; rounding margin checked by the oracle test).
+struct MkBrArgs {
+    const int32_t *bara;  // [R][P*n+1]
+    const cplx *bk;       // [P][n][2*L*P + 2*L][8][64] spectra (engine order, scaled 1/M)
+    int32_t *ext;         // [R][P*N+1]
+    Tables T;
+    Gadget g;
+    int32_t n;
+    int32_t mu;
+};
+
+__device__ __forceinline__ void fft_fwd_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+    x1_store_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_b(lane, x, xch);
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    WAVE_LDS_FENCE();
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+    WAVE_LDS_FENCE();
+    dft8<false>(x);
+}
+
+__device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    dft8<true>(x);
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    dft8<true>(x);
+    WAVE_LDS_FENCE();
+    x1_store_b(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f[q]);
+    dft8<true>(x);
+}
+
+template <int L, int PARTY>
+__device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
+                                               cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask)
+{
+    constexpr int NP = 2;                         // parties
+    constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit)
+    const int beta = P.g.log2_base;
+#pragma unroll 1
+    for (int j = 0; j < P.n; j++) {
+        const int a = bara[PARTY * P.n + j] & (2 * kN - 1);
+        const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
+        cplx out[NP + 1][8];
+#pragma unroll
+        for (int d = 0; d <= NP; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
+            int32_t temp[16];
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                // key polys for this transform (mk_internals.jl:371-385)
+                const cplx *k_party, *k_body, *k_other = nullptr;
+                if (s < NP) {
+                    k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
+                    k_body = key + (size_t)(p * NP + s) * kM;                   // x[p, s]      -> b'
+                    if (s != PARTY) k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;   // y[p, party] -> a'_s
+                } else {
+                    k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
+                    k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
+                }
+                cplx kv[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_party[k2 * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kv[k2], out[PARTY][k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_body[k2 * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kv[k2], out[NP][k2]);
+                if (s < NP && s != PARTY) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_other[k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[s < NP ? s : 0][k2] = cfma(x[k2], kv[k2], out[s < NP ? s : 0][k2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d <= NP; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2(out[d], accr);
+            store_acc<2>(lane, accr, acc_lds + d * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
+{
+    constexpr int NP = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [kXchElems]
+    cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (NP * P.n + 1);
+    const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
+        const int barb = bara[NP * P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = 0;
+            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+    // party-major double loop (mk_internals.jl:475-476)
+    mk_party_steps<L, 0>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
+    mk_party_steps<L, 1>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
+
+    // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
+    int32_t *ext = P.ext + w * (NP * kN + 1);
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[c * kN] = v;
+            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
+}
+
 // Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
 // (the analogue of forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
@@ -579,21 +752,24 @@ struct Ks3Args {
     const int32_t *ext;     // [R][kN+1]
     const int32_t *ksp;     // [kN][t][base-1][stride]  rows padded to a multiple of 4 words
     const int32_t *e0, *e1, *dst;
-    int32_t *out;           // [B][n+1], pre-initialised to (0, ..., 0, b) by ks3_init_kernel
+    int32_t *out;           // [B][out_stride], pre-initialised to (0, ..., 0, b) by ks3_init_kernel
     int32_t n, kN, t, log2_base, stride, G;
+    // generalised addressing (single key: in_stride = kN+1, in_off = 0, in_b = kN, out_stride = n+1,
+    // out_off = 0, out_b = n; multi-key party p: in_off = p*N, out_off = p*n, out_b = P*n)
+    int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
 };
 
 __global__ void ks3_init_kernel(Ks3Args P)
 {
     const int g = blockIdx.x;
     const size_t og = P.dst ? (size_t)P.dst[g] : (size_t)g;
-    int32_t *o = P.out + og * (P.n + 1);
-    for (int w = threadIdx.x; w < P.n; w += blockDim.x) o[w] = 0;
+    int32_t *o = P.out + og * P.out_stride;
+    for (int w = threadIdx.x; w < P.out_b; w += blockDim.x) o[w] = 0;
     if (threadIdx.x == 0) {
-        uint32_t b = (uint32_t)P.ext[(size_t)P.e0[g] * (P.kN + 1) + P.kN];               // keyswitch.jl:50
+        uint32_t b = (uint32_t)P.ext[(size_t)P.e0[g] * P.in_stride + P.in_b];               // keyswitch.jl:50
         const int e1 = P.e1 ? P.e1[g] : -1;
-        if (e1 >= 0) b += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + P.kN] + (1u << 29);  // gates.jl:174
-        o[P.n] = (int32_t)b;
+        if (e1 >= 0) b += (uint32_t)P.ext[(size_t)e1 * P.in_stride + P.in_b] + (1u << 29);  // gates.jl:174
+        o[P.out_b] = (int32_t)b;
     }
 }
 
@@ -625,9 +801,9 @@ __global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
     for (int idx = tid; idx < G * slen; idx += 128) {
         const int g = idx / slen, ii = idx % slen;
         const int gg = min(g0 + g, P.G - 1);
-        uint32_t ai = (uint32_t)P.ext[(size_t)P.e0[gg] * (P.kN + 1) + i0 + ii];
+        uint32_t ai = (uint32_t)P.ext[(size_t)P.e0[gg] * P.in_stride + P.in_off + i0 + ii];
         const int e1 = P.e1 ? P.e1[gg] : -1;
-        if (e1 >= 0) ai += (uint32_t)P.ext[(size_t)e1 * (P.kN + 1) + i0 + ii];
+        if (e1 >= 0) ai += (uint32_t)P.ext[(size_t)e1 * P.in_stride + P.in_off + i0 + ii];
         abar[g][ii] = (int32_t)(ai + prec_offset);                           // keyswitch.jl:59
     }
     __syncthreads();
@@ -674,16 +850,17 @@ __global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
     }
 
     if (!active) return;
-    const int n1 = P.n + 1;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int gg = g0 + g;
         if (gg >= P.G) break;
         const size_t og = P.dst ? (size_t)P.dst[gg] : (size_t)gg;
-        int32_t *o = P.out + og * n1;
+        int32_t *o = P.out + og * P.out_stride;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (w0 + q < n1) atomicAdd(reinterpret_cast<unsigned int *>(o + w0 + q), acc[g][q]);
+        for (int q = 0; q < 4; q++) {
+            if (w0 + q < P.n) atomicAdd(reinterpret_cast<unsigned int *>(o + P.out_off + w0 + q), acc[g][q]);
+            else if (w0 + q == P.n) atomicAdd(reinterpret_cast<unsigned int *>(o + P.out_b), acc[g][q]);   // mk_internals.jl:409
+        }
     }
 }
 
@@ -746,6 +923,12 @@ struct tfhe_ctx {
     int32_t *d_ks = nullptr;
     int32_t *d_ksp = nullptr;   int ks_stride = 0;   // row-padded copy for keyswitch_kernel_v3
     bool have_bk = false, have_ks = false;
+    // multi-key (2 parties)
+    cplx *d_mk_bk = nullptr;
+    int32_t *d_mk_ksp = nullptr;   // [P] row-padded keyswitch keys back to back
+    size_t mk_ksp_words = 0;       // words per party in d_mk_ksp
+    int mk_parties = 0;
+    bool have_mk_bk = false, have_mk_ks = false;
 
     // workspaces
     DevBuf bara, ext, map, io[4];
@@ -854,6 +1037,8 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_ks) (void)hipFree(c->d_ks);
     if (c->d_ksp) (void)hipFree(c->d_ksp);
+    if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
+    if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
     c->bara.release(); c->ext.release(); c->map.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
@@ -992,6 +1177,7 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
         Ks3Args a3;
         a3.ext = ext; a3.ksp = c->d_ksp; a3.e0 = e0; a3.e1 = e1; a3.dst = dst; a3.out = out;
         a3.n = c->P.n; a3.kN = k.kN; a3.t = c->P.ks_t; a3.log2_base = 2; a3.stride = c->ks_stride; a3.G = (int)G;
+        a3.in_stride = k.kN + 1; a3.in_off = 0; a3.in_b = k.kN; a3.out_stride = n1; a3.out_off = 0; a3.out_b = c->P.n;
         hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)G), dim3(256), 0, s, a3);
         const unsigned tiles = (unsigned)((G + KS3_G - 1) / KS3_G);
         hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, a3);
@@ -1214,20 +1400,117 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     return TFHE_OK;
 }
 
-int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *, int32_t)
+int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t parties)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+    if (!bk) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: NULL key pointer");
+    if (parties != 2 || c->P.parties < 2) return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_bootstrap_key: this build supports exactly 2 parties on a context created with parties >= 2");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t per = (size_t)2 * c->P.bs_l * parties + 2 * c->P.bs_l;
+    const size_t npolys = (size_t)parties * c->P.n * per;
+    if (c->d_mk_bk) { (void)hipFree(c->d_mk_bk); c->d_mk_bk = nullptr; c->have_mk_bk = false; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * kM * sizeof(cplx)));
+    void *d_in = nullptr;
+    HIP_TRY(c, hipMalloc(&d_in, npolys * kN * 4));
+    hipError_t e = hipMemcpyAsync(d_in, bk, npolys * kN * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    if (e != hipSuccess) return c->set_err(TFHE_ERR_DEVICE, "mk_load_bootstrap_key: %s", hipGetErrorString(e));
+    c->mk_parties = parties;
+    c->have_mk_bk = true;
+    return TFHE_OK;
 }
-int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *, int32_t)
+
+int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parties)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+    if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: NULL key pointer");
+    if (parties != 2 || c->P.parties < 2) return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: this build supports exactly 2 parties on a context created with parties >= 2");
+    if (c->P.ks_log2_base != 2 || c->P.ks_t % 4 != 0 || c->P.N % KS3_SLICES != 0 || c->P.N / KS3_SLICES > 128)
+        return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: keyswitch base must be 4 and t a multiple of 4");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
+    const size_t rows = (size_t)c->P.N * c->P.ks_t * ((1u << c->P.ks_log2_base) - 1);   // per party (k = 1)
+    if (c->d_mk_ksp) { (void)hipFree(c->d_mk_ksp); c->d_mk_ksp = nullptr; c->have_mk_ks = false; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_mk_ksp, (size_t)parties * rows * stride * 4));
+    HIP_TRY(c, hipMemset(c->d_mk_ksp, 0, (size_t)parties * rows * stride * 4));
+    HIP_TRY(c, hipMemcpy2D(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice));
+    c->mk_ksp_words = rows * stride;
+    c->ks_stride = (int)stride;
+    c->have_mk_ks = true;
+    return TFHE_OK;
 }
-int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *, const int32_t *, int32_t *, int64_t)
+
+int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *in1, int32_t *out, int64_t B)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return c->set_err(TFHE_ERR_UNSUPPORTED, "multi-key path not built yet");
+    if (B < 0 || (B > 0 && (!in0 || !in1 || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_gate_nand_batch: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    if (!c->have_mk_bk || !c->have_mk_ks) return c->set_err(TFHE_ERR_NO_KEY, "mk_gate_nand_batch: multi-key keys not loaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int NP = c->mk_parties, n = c->P.n, nw = NP * n + 1, ew = NP * kN + 1;
+    const size_t bytes = (size_t)B * nw * 4;
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c, c->io[i].reserve(bytes));
+        HIP_TRY(c, hipMemcpyAsync(c->io[i].p, i == 0 ? in0 : in1, bytes, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, c->io[3].reserve(bytes));
+    HIP_TRY(c, c->bara.reserve(bytes));
+    HIP_TRY(c, c->ext.reserve((size_t)B * ew * 4));
+    // maps: rot_gate[g] = g, kind = NAND, e0[g] = g
+    int32_t rc = ensure_host_map(c, (size_t)B * 5);
+    if (rc) return rc;
+    int32_t *h_gate = (int32_t *)c->h_map;
+    uint8_t *h_kind = (uint8_t *)(h_gate + B);
+    for (int64_t g = 0; g < B; g++) { h_gate[g] = (int32_t)g; h_kind[g] = TFHE_GATE_NAND; }
+    HIP_TRY(c, c->map.reserve((size_t)B * 5));
+    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)B * 5, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(c->map_ev, s));
+    c->map_pending = true;
+    const int32_t *d_gate = (const int32_t *)c->map.p;
+    const uint8_t *d_kind = (const uint8_t *)(d_gate + B);
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    // mk_gate_nand prologue (mk_gates.jl:8-10) = the NAND affine form over P*n+1 words, then mod-switch
+    hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)B), dim3(256), 0, s, (const int32_t *)c->io[0].p, (const int32_t *)c->io[1].p,
+                       (const int32_t *)nullptr, d_gate, d_kind, (int32_t *)c->bara.p, NP * n, ilog2i(2 * c->P.N));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    MkBrArgs a;
+    a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
+    a.n = n; a.mu = (int32_t)(1u << 29);
+    const size_t lds = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+    switch (c->P.bs_l) {
+    case 2: hipLaunchKernelGGL((mk_blind_rotate_kernel<2>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+    case 3: hipLaunchKernelGGL((mk_blind_rotate_kernel<3>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((mk_blind_rotate_kernel<4>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "mk blind rotate: bs_l = %d unsupported", c->P.bs_l);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    // mk_keyswitch (mk_internals.jl:397-411): per party a single-key keyswitch of its mask column with b = 0
+    Ks3Args k3;
+    k3.ext = (const int32_t *)c->ext.p; k3.e0 = d_gate; k3.e1 = nullptr; k3.dst = nullptr; k3.out = (int32_t *)c->io[3].p;
+    k3.n = n; k3.kN = kN; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
+    k3.in_stride = ew; k3.in_b = NP * kN; k3.out_stride = nw; k3.out_b = NP * n;
+    k3.in_off = 0; k3.out_off = 0; k3.ksp = c->d_mk_ksp;
+    hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)B), dim3(256), 0, s, k3);
+    const unsigned tiles = (unsigned)((B + KS3_G - 1) / KS3_G);
+    for (int p = 0; p < NP; p++) {
+        k3.in_off = p * kN; k3.out_off = p * n; k3.ksp = c->d_mk_ksp + (size_t)p * c->mk_ksp_words;
+        hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, k3);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->timing_valid = true;
+    c->last_rotations = B;
+    return TFHE_OK;
 }
 
 int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)

@@ -70,3 +70,32 @@ def negacyclic_mul_binary(s, a):
         return np.rint(y.real).astype(np.int64)
 
     return wrap32(prod(lo) + (prod(hi) << 16))
+
+
+def negacyclic_mul_small(d, a):
+    """(d * a) mod (X^N + 1, 2^32) for small-integer polynomials d[..., N] (|d| <= 2^12, e.g. gadget
+    digits or binary keys) and Int32 polynomials a[..., N], broadcasting over leading axes.
+    Exact: a is split into 16-bit halves so every FFT value stays below 2^40 (float64 has 53 bits)."""
+    d = np.asarray(d, dtype=np.float64)
+    a = np.asarray(a)
+    N = d.shape[-1]
+    au = a.astype(np.int64) & 0xFFFFFFFF
+    lo, hi = (au & 0xFFFF).astype(np.float64), (au >> 16).astype(np.float64)
+    j = np.arange(N)
+    tw = np.exp(1j * np.pi * j / N)
+    fd = np.fft.fft(d * tw, axis=-1)
+
+    def prod(x):
+        y = np.fft.ifft(np.fft.fft(x * tw, axis=-1) * fd, axis=-1) * np.conj(tw)
+        return np.rint(y.real).astype(np.int64)
+
+    return wrap32(prod(lo) + (prod(hi) << 16))
+
+
+def decompose(poly, l, log2_base):
+    """tgsw.jl:99-117 on the host (used by MK key expansion): int32 [..., N] -> int32 [l, ..., N]."""
+    c = np.asarray(poly, np.int32).astype(np.int64)
+    offset = sum(1 << (32 - p * log2_base) for p in range(1, l + 1)) * (1 << (log2_base - 1))
+    t = wrap32(c + offset).astype(np.int64)
+    mask, half = (1 << log2_base) - 1, 1 << (log2_base - 1)
+    return np.stack([(((t >> (32 - p * log2_base)) & mask) - half) for p in range(1, l + 1)]).astype(np.int32)
