@@ -149,3 +149,21 @@ def test_full_batch_4096_properties(tfhe, orc, keys80, eng80):
     assert np.array_equal(got2, got[perm])
     assert eng80.last_rotation_count() == B
     assert eng80.last_timing_ms(0) > 0 and eng80.last_timing_ms(1) > 0
+
+
+def test_tutorial_encrypted_minimum(tfhe, keys80, eng80):
+    """examples/tutorial.jl:42-78 end to end: the 16-bit encrypted minimum of 2017 and 42 decrypts to 42
+    (16 XNOR + 32 MUX = 80 blind rotations, 48 keyswitches), through the reference-named gate API."""
+    K = keys80
+    a_bits = [(2017 >> i) & 1 == 1 for i in range(16)]          # tutorial.jl:24-26
+    b_bits = [(42 >> i) & 1 == 1 for i in range(16)]            # :29-31
+    a = [tfhe.encrypt(K.rng, K.sk, bit) for bit in a_bits]
+    b = [tfhe.encrypt(K.rng, K.sk, bit) for bit in b_bits]
+    carry = tfhe.gate_constant(K.ck, False)                     # :52
+    for i in range(16):                                         # :54-56, compare_bit :42-45
+        tmp = tfhe.gate_xnor(K.ck, a[i], b[i])
+        carry = tfhe.gate_mux(K.ck, tmp, carry, a[i])
+    sel = tfhe.LweSampleArray.from_samples([carry] * 16)
+    res = tfhe.gate_mux(K.ck, sel, tfhe.LweSampleArray.from_samples(b), tfhe.LweSampleArray.from_samples(a))   # :60 as one batch
+    bits = tfhe.decrypt(K.sk, res)
+    assert sum(int(v) << i for i, v in enumerate(bits)) == 42   # :72-77 "Answer: 42"
