@@ -40,8 +40,9 @@ def test_gpu_reproduces_golden(tfhe, kat):
     assert np.array_equal(e.gates(kat["ops"], kat["in0"], kat["in1"], kat["in2"]), kat["out"])
     assert np.array_equal(e.bootstrap(2**29, kat["in0"][:8], with_keyswitch=False), kat["ext"])
     assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
-    for v in (1, 2, 3):   # every kernel variant gives the same words
-        e.set_option("br_variant", v)
-        e.set_option("ks_variant", v)
+    for bv, kv in ((1, 1), (2, 2), (3, 3), (2, 4)):   # every kernel variant gives the same words
+        e.set_option("br_variant", bv)
+        e.set_option("ks_variant", kv)
         assert np.array_equal(e.gates(kat["ops"], kat["in0"], kat["in1"], kat["in2"]), kat["out"])
+        assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
     e.close()

@@ -864,6 +864,166 @@ __global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
     }
 }
 
+// ---- keyswitch v4: int8 MFMA ------------------------------------------------------------------------
+// out[g][w] = b_g [w == n] - sum_{i,j} KS[i][j][d(g,i,j)][w]   (keyswitch.jl:45-80, no row for digit 0)
+// cast as an exact integer contraction  C = A x B:
+//   A[g][(i, j, hh)] = 1 if d(g,i,j) == hh            one-hot digits, generated in registers
+//   B[(i, j, hh)][(plane, w)] = signed byte `plane` of KS[i][j][hh-1][w]   (hh = 0: zero row)
+// with value = sum_plane byte_plane * 256^plane (mod 2^32), bytes in [-128, 127], so every int32 partial
+// sum is exact (|C| <= kN*t*128 = 2^20) and out = b - sum_plane C_plane << 8*plane (mod 2^32).
+// v_mfma_i32_32x32x32_i8: one instruction covers 32 samples x 32 (plane, word) columns x 32 K-slots = one
+// mask word i (8 digit positions x 4 digit values).  Only the pairing of A's and B's K-slots matters:
+// lane half h, byte 4q+hh <-> (digit position 4h+q, digit value hh) for both operands.
+// A wave owns 64 samples x 32 words x 4 planes (128 accumulator registers); the 4 waves of a block take
+// 4 sample groups and share the B stream through L1.  Requires base 4 and t = 8.
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+
+struct Ks4Args {
+    const int32_t *ext;
+    const i32x4 *bmat;      // [kN][wtiles][4 planes][64 lanes] 16-byte B fragments
+    const int32_t *e0, *e1, *dst;
+    int32_t *out;
+    int32_t n, kN, G, wtiles;
+    int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
+    int32_t add_b;          // 1: out[out_b] = ext b (+ MUX constant) - sum; 0 (MK party > 0): accumulate into out_b
+};
+
+// balanced signed byte `plane` of a 32-bit word: value == sum_p sbyte(value, p) * 256^p (mod 2^32)
+__host__ __device__ inline int32_t signed_byte_plane(uint32_t v, int plane)
+{
+    int32_t s = 0;
+    for (int p = 0; p <= plane; p++) {
+        const uint32_t u = v & 255u;
+        s = u >= 128u ? (int32_t)u - 256 : (int32_t)u;
+        v = (v - (uint32_t)s) >> 8;
+    }
+    return s;
+}
+
+// key preparation: canonical Int32 [kN][8][3][n+1] -> B fragments
+__global__ void ks4_prepare_kernel(const int32_t *__restrict__ ks, i32x4 *__restrict__ bmat, int n, int kN, int wtiles)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (i, wtile, plane, lane)
+    const size_t total = (size_t)kN * wtiles * 4 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int plane = (int)((idx >> 6) & 3);
+    const int wt = (int)((idx >> 8) % wtiles);
+    const int i = (int)((idx >> 8) / wtiles);
+    const int c = lane & 31, h = lane >> 5;
+    const int w = wt * 32 + c;
+    i32x4 frag;
+    for (int q = 0; q < 4; q++) {
+        const int j = 4 * h + q;                                            // digit position (0-based)
+        uint32_t word = 0;
+        for (int hh = 1; hh <= 3; hh++) {
+            int32_t sb = 0;
+            if (w <= n) sb = signed_byte_plane((uint32_t)ks[(((size_t)i * 8 + j) * 3 + (hh - 1)) * (n + 1) + w], plane);
+            word |= ((uint32_t)sb & 255u) << (8 * hh);
+        }
+        frag[q] = (int32_t)word;
+    }
+    bmat[idx] = frag;
+}
+
+__global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
+{
+    constexpr int MT = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int wt = blockIdx.y;
+    const int gbase = (blockIdx.x * 4 + wave) * (32 * MT);
+    if (gbase >= P.G) return;
+
+    const int32_t *row0[MT], *row1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int gg = min(gbase + mt * 32 + c, P.G - 1);
+        row0[mt] = P.ext + (size_t)P.e0[gg] * P.in_stride + P.in_off;
+        const int e1 = P.e1 ? P.e1[gg] : -1;
+        row1[mt] = e1 >= 0 ? P.ext + (size_t)e1 * P.in_stride + P.in_off : nullptr;
+    }
+    const uint32_t prec_offset = 1u << 15;                                   // 2^(32 - (1 + 2*8))   keyswitch.jl:58
+
+    i32x16 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][pl][r] = 0;
+
+    const i32x4 *bp = P.bmat + (size_t)wt * 4 * 64 + lane;
+    const size_t bstep = (size_t)P.wtiles * 4 * 64;                          // fragments per mask word i
+    i32x4 bcur[4], bnxt[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) bcur[pl] = bp[pl * 64];
+
+    for (int i4 = 0; i4 < P.kN; i4 += 4) {
+        // 4 consecutive mask words of this lane's samples (MUX: sum of two extracted samples, gates.jl:174)
+        uint32_t a4[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                uint32_t v = (uint32_t)row0[mt][i4 + ii];
+                if (row1[mt]) v += (uint32_t)row1[mt][i4 + ii];
+                a4[mt][ii] = v + prec_offset;                                // keyswitch.jl:59
+            }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = i4 + ii;
+            const i32x4 *bn = bp + (size_t)(i + 1 < P.kN ? i + 1 : i) * bstep;
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) bnxt[pl] = bn[pl * 64];
+            i32x4 afrag[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // digit position j = 4h+q (0-based) occupies bits [30-2j, 31-2j]   keyswitch.jl:65-67
+                    const uint32_t d8 = (a4[mt][ii] >> (27 - 2 * (4 * h + q))) & 24u;   // 8 * digit
+                    afrag[mt][q] = (int32_t)(1u << d8);                      // one-hot byte
+                }
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt][pl] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[mt], bcur[pl], acc[mt][pl], 0, 0, 0);
+#pragma unroll
+            for (int pl = 0; pl < 4; pl++) bcur[pl] = bnxt[pl];
+        }
+    }
+
+    // epilogue: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int w = wt * 32 + c;
+    if (w > P.n) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int gg = gbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (gg >= P.G) continue;
+            uint32_t sum = (uint32_t)acc[mt][0][r] + ((uint32_t)acc[mt][1][r] << 8) + ((uint32_t)acc[mt][2][r] << 16) +
+                           ((uint32_t)acc[mt][3][r] << 24);
+            const size_t og = P.dst ? (size_t)P.dst[gg] : (size_t)gg;
+            int32_t *o = P.out + og * P.out_stride;
+            if (w < P.n) {
+                o[P.out_off + w] = (int32_t)(0u - sum);
+            } else {                                                         // the b word
+                if (P.add_b) {
+                    uint32_t b = (uint32_t)P.ext[(size_t)P.e0[gg] * P.in_stride + P.in_b];             // keyswitch.jl:50
+                    const int e1 = P.e1 ? P.e1[gg] : -1;
+                    if (e1 >= 0) b += (uint32_t)P.ext[(size_t)e1 * P.in_stride + P.in_b] + (1u << 29);   // gates.jl:174
+                    o[P.out_b] = (int32_t)(b - sum);
+                } else {
+                    o[P.out_b] = (int32_t)((uint32_t)o[P.out_b] - sum);      // mk_internals.jl:409 (launches are stream-ordered)
+                }
+            }
+        }
+}
+
 // gate_not / gate_constant / copy (gates.jl:76-93)
 __global__ void trivial_gates_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ gates,
                                      const uint8_t *__restrict__ ops, int32_t *__restrict__ out, int n)
@@ -910,7 +1070,7 @@ struct tfhe_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
     bool timing_valid = false;
     int64_t last_rotations = 0;
-    int ks_variant = 3;          // 1 = one workgroup per sample, 2 = gate-tiled, 3 = tiled + sliced + XCD-aware (default)
+    int ks_variant = 4;          // 1 = one workgroup per sample, 2 = gate-tiled, 3 = tiled + sliced + XCD-aware, 4 = int8 MFMA (default)
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
     // tables
@@ -922,6 +1082,8 @@ struct tfhe_ctx {
     cplx *d_bk = nullptr;       size_t bk_polys = 0;
     int32_t *d_ks = nullptr;
     int32_t *d_ksp = nullptr;   int ks_stride = 0;   // row-padded copy for keyswitch_kernel_v3
+    void *d_ks4 = nullptr;      int ks4_wtiles = 0;  // MFMA B fragments for keyswitch_kernel_v4 (base 4, t = 8)
+    void *d_mk_ks4 = nullptr;   size_t mk_ks4_frags = 0;
     bool have_bk = false, have_ks = false;
     // multi-key (2 parties)
     cplx *d_mk_bk = nullptr;
@@ -1037,6 +1199,8 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_ks) (void)hipFree(c->d_ks);
     if (c->d_ksp) (void)hipFree(c->d_ksp);
+    if (c->d_ks4) (void)hipFree(c->d_ks4);
+    if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
     c->bara.release(); c->ext.release(); c->map.release();
@@ -1120,6 +1284,17 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
         HIP_TRY(c, hipMemcpy2D(c->d_ksp, stride * 4, c->d_ks, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice));
         c->ks_stride = (int)stride;
     }
+    if (c->d_ks4) { (void)hipFree(c->d_ks4); c->d_ks4 = nullptr; }
+    if (c->P.ks_log2_base == 2 && c->P.ks_t == 8 && (c->P.k * c->P.N) % 4 == 0) {
+        const int kNn = c->P.k * c->P.N, wtiles = (c->P.n + 1 + 31) / 32;
+        const size_t frags = (size_t)kNn * wtiles * 4 * 64;
+        HIP_TRY(c, hipMalloc(&c->d_ks4, frags * 16));
+        hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)c->d_ks,
+                           (i32x4 *)c->d_ks4, c->P.n, kNn, wtiles);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->ks4_wtiles = wtiles;
+    }
     c->have_ks = true;
     return TFHE_OK;
 }
@@ -1172,7 +1347,16 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     k.out = out;
     k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
     const int n1 = c->P.n + 1;
-    if (c->ks_variant == 3 && c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && k.kN % (KS3_SLICES * 1) == 0 &&
+    if (c->ks_variant == 4 && c->d_ks4) {
+        Ks4Args a4;
+        a4.ext = ext; a4.bmat = (const i32x4 *)c->d_ks4; a4.e0 = e0; a4.e1 = e1; a4.dst = dst; a4.out = out;
+        a4.n = c->P.n; a4.kN = k.kN; a4.G = (int)G; a4.wtiles = c->ks4_wtiles;
+        a4.in_stride = k.kN + 1; a4.in_off = 0; a4.in_b = k.kN; a4.out_stride = n1; a4.out_off = 0; a4.out_b = c->P.n; a4.add_b = 1;
+        hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((G + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
+    if ((c->ks_variant == 3 || c->ks_variant == 4) && c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && k.kN % (KS3_SLICES * 1) == 0 &&
         k.kN / KS3_SLICES <= 128) {
         Ks3Args a3;
         a3.ext = ext; a3.ksp = c->d_ksp; a3.e0 = e0; a3.e1 = e1; a3.dst = dst; a3.out = out;
@@ -1441,6 +1625,24 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
     HIP_TRY(c, hipMemcpy2D(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice));
     c->mk_ksp_words = rows * stride;
     c->ks_stride = (int)stride;
+    if (c->d_mk_ks4) { (void)hipFree(c->d_mk_ks4); c->d_mk_ks4 = nullptr; }
+    if (c->P.ks_t == 8) {   // MFMA fragments per party (keyswitch_kernel_v4)
+        const int wtiles = (c->P.n + 1 + 31) / 32;
+        const size_t frags = (size_t)c->P.N * wtiles * 4 * 64, words = rows * n1;
+        int32_t *d_tmp = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&d_tmp, words * 4));
+        HIP_TRY(c, hipMalloc(&c->d_mk_ks4, (size_t)parties * frags * 16));
+        for (int p = 0; p < parties; p++) {
+            HIP_TRY(c, hipMemcpy(d_tmp, ks + (size_t)p * words, words * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_tmp,
+                               (i32x4 *)c->d_mk_ks4 + (size_t)p * frags, c->P.n, c->P.N, wtiles);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        (void)hipFree(d_tmp);
+        c->mk_ks4_frags = frags;
+        c->ks4_wtiles = wtiles;
+    }
     c->have_mk_ks = true;
     return TFHE_OK;
 }
@@ -1493,6 +1695,24 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     // mk_keyswitch (mk_internals.jl:397-411): per party a single-key keyswitch of its mask column with b = 0
+    if (c->ks_variant == 4 && c->d_mk_ks4) {
+        Ks4Args a4;
+        a4.ext = (const int32_t *)c->ext.p; a4.e0 = d_gate; a4.e1 = nullptr; a4.dst = nullptr; a4.out = (int32_t *)c->io[3].p;
+        a4.n = n; a4.kN = kN; a4.G = (int)B; a4.wtiles = c->ks4_wtiles;
+        a4.in_stride = ew; a4.in_b = NP * kN; a4.out_stride = nw; a4.out_b = NP * n;
+        for (int p = 0; p < NP; p++) {
+            a4.in_off = p * kN; a4.out_off = p * n; a4.add_b = (p == 0);
+            a4.bmat = (const i32x4 *)c->d_mk_ks4 + (size_t)p * c->mk_ks4_frags;
+            hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((B + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->timing_valid = true;
+        c->last_rotations = B;
+        return TFHE_OK;
+    }
     Ks3Args k3;
     k3.ext = (const int32_t *)c->ext.p; k3.e0 = d_gate; k3.e1 = nullptr; k3.dst = nullptr; k3.out = (int32_t *)c->io[3].p;
     k3.n = n; k3.kN = kN; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
@@ -1542,7 +1762,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "ks_variant")) {
-        if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 2 or 3");
+        if (value < 1 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1..4");
         c->ks_variant = (int)value;
         return TFHE_OK;
     }
