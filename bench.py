@@ -140,12 +140,12 @@ def main():
             "outputs_decrypt_to_nand": ok_decrypt,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "blind_rotate_kernel",
+                "kernel": "blind_rotate_kernel_v3",
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                "traffic": traffic_from_profiles("blind_rotate_kernel_v3", rotations_per_step),
                 "bytes_per_unit": BR_BYTES[args.params],
                 "units_per_launch": rotations_per_step,
                 "avg_launch_ms": br_avg_s * 1e3,
@@ -161,6 +161,27 @@ def main():
     ck.close()
     if not ok_decrypt:
         sys.exit("bench.py: GPU outputs did not decrypt to NAND")
+
+
+def traffic_from_profiles(kernel_substr, units_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<tag>/traffic.json, written by tools/prof_summary.py: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024,
+    separate --pmc passes of this same command).  Only reported when that profile was taken at the same
+    number of rotations per launch; otherwise null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        meta = d.get("_meta", {})
+        if meta.get("units_per_launch") not in (None, units_per_launch):
+            continue
+        for k, v in d.items():
+            if kernel_substr in k:
+                best = v["hbm_bytes_per_launch"]
+    return best
 
 
 def cpu_baseline(tfhe, params, ck, hx, hy, gpu_out, args):
