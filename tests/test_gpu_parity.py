@@ -167,3 +167,23 @@ def test_tutorial_encrypted_minimum(tfhe, keys80, eng80):
     res = tfhe.gate_mux(K.ck, sel, tfhe.LweSampleArray.from_samples(b), tfhe.LweSampleArray.from_samples(a))   # :60 as one batch
     bits = tfhe.decrypt(K.sk, res)
     assert sum(int(v) << i for i, v in enumerate(bits)) == 42   # :72-77 "Answer: 42"
+
+
+def test_gate_parity_mask_size_2(tfhe, orc):
+    """tlwe_mask_size = 2 (api.jl:30 keyword): 3-polynomial accumulator kernel, 2N-word keyswitch."""
+    from conftest import KeySet
+    K = KeySet(tfhe, orc, tfhe.tfhe_parameters_80(tlwe_mask_size=2), seed=77)
+    eng = K.ck.engine(0)
+    combos = list(itertools.product((False, True), repeat=3))
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    for name in ("NAND", "MUX", "XNOR"):
+        ops = np.full(8, tfhe.OPCODES[name], np.uint8)
+        got = eng.gates(ops, *ins)
+        assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=8))
+    got = eng.gates(np.full(8, tfhe.OPCODES["MUX"], np.uint8), *ins)
+    assert list(tfhe.decrypt(K.sk, got)) == [bool(y if x else z) for x, y, z in combos]
+    x = K.rng.integers(-2**31, 2**31, size=(4, 501), dtype=np.int64).astype(np.int32)
+    ext = eng.bootstrap(2**29, x, with_keyswitch=False)
+    assert ext.shape == (4, 2049) and np.array_equal(ext, K.oracle.bootstrap(2**29, x, with_keyswitch=False))
+    assert np.array_equal(eng.keyswitch(ext), K.oracle.keyswitch(ext))
+    K.ck.close()

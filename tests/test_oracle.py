@@ -167,3 +167,16 @@ def test_noiseless_bootstrap_kat(orc, tfhe):
         s = tlwe_key.key.reshape(-1).astype(np.int64)
         ph = (int(ext[0, -1]) - int(ext[0, :-1].astype(np.int64) @ s)) % 2**32
         assert ph == want % 2**32
+
+
+def test_truth_table_mask_size_2(orc, tfhe):
+    """tfhe_parameters_80(tlwe_mask_size=2) (api.jl:30): NAND and MUX truth tables on the oracle."""
+    from conftest import KeySet
+    K = KeySet(tfhe, orc, tfhe.tfhe_parameters_80(tlwe_mask_size=2), seed=77)
+    assert K.ck.bootstrap_key.shape == (500, 2, 3, 3, 1024) and K.ck.keyswitch_key.shape == (2048, 8, 3, 501)
+    combos = list(itertools.product((False, True), repeat=3))
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    out = K.oracle.gates(np.full(8, orc.OPS["MUX"], np.uint8), *ins, nthreads=8)
+    assert list(tfhe.decrypt(K.sk, out)) == [bool(y if x else z) for x, y, z in combos]
+    out = K.oracle.gates(np.full(8, orc.OPS["NAND"], np.uint8), *ins, nthreads=8)
+    assert list(tfhe.decrypt(K.sk, out)) == [not (x and y) for x, y, z in combos]

@@ -549,6 +549,100 @@ __global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
     if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
 }
 
+// ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
+// Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
+// 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
+template <int L>
+__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
+{
+    constexpr int K1 = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
+    cplx *tw2_lds = xch + kXchElems;
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = 0;
+            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN - 1);
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + lane;
+        cplx out[K1][8];
+#pragma unroll
+        for (int d = 0; d < K1; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll 1
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[16];
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
+#pragma unroll
+                for (int co = 0; co < K1; co++) {
+                    cplx kv[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(co * 8 + k2) * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < K1; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2(out[d], accr);
+            store_acc<2>(lane, accr, acc_lds + d * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+    // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
+    int32_t *ext = P.ext + w * (2 * kN + 1);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[c * kN] = v;
+            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
+}
+
 // Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
 // (the analogue of forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
@@ -1153,7 +1247,8 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d only (got %d)", kN, p.N);
         return fail(TFHE_ERR_UNSUPPORTED, buf);
     }
-    if (p.k != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 only");
+    if (p.k != 1 && p.k != 2) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 or 2");
+    if (p.k != 1 && p.parties != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key needs tlwe_mask_size 1 (as the reference, mk_internals.jl:89-91)");
     if (p.bs_l > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 unsupported");
     if (p.n + 1 > 1024) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: lwe_size + 1 > 1024 unsupported");
 
@@ -1310,6 +1405,18 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.g = c->g;
     a.n = c->P.n;
     a.mu = mu;
+    if (c->P.k == 2) {
+        const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+        switch (c->P.bs_l) {
+        case 1: hipLaunchKernelGGL((blind_rotate_kernel_k2<1>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
+        case 2: hipLaunchKernelGGL((blind_rotate_kernel_k2<2>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
+        case 3: hipLaunchKernelGGL((blind_rotate_kernel_k2<3>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
+        case 4: hipLaunchKernelGGL((blind_rotate_kernel_k2<4>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
+        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
     if (c->br_variant >= 2) {
         const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
 #define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK>), dim3((unsigned)R), dim3(64), lds3, s, a)
