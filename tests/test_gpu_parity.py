@@ -187,3 +187,30 @@ def test_gate_parity_mask_size_2(tfhe, orc):
     assert ext.shape == (4, 2049) and np.array_equal(ext, K.oracle.bootstrap(2**29, x, with_keyswitch=False))
     assert np.array_equal(eng.keyswitch(ext), K.oracle.keyswitch(ext))
     K.ck.close()
+
+
+def test_gate_parity_synthetic_n2048(tfhe, orc):
+    """BASELINE config 4b (synthetic N = 2048, l = 3, beta = 7): two-wave blind-rotate kernel."""
+    from conftest import KeySet
+    from test_oracle import synthetic_2048
+    K = KeySet(tfhe, orc, synthetic_2048(tfhe), seed=2048)
+    eng = K.ck.engine(0)
+    combos = list(itertools.product((False, True), repeat=3))
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    for name in ("NAND", "MUX"):
+        ops = np.full(8, tfhe.OPCODES[name], np.uint8)
+        got = eng.gates(ops, *ins)
+        assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=8))
+    got = eng.gates(np.full(8, tfhe.OPCODES["MUX"], np.uint8), *ins)
+    assert list(tfhe.decrypt(K.sk, got)) == [bool(y if x else z) for x, y, z in combos]
+    x = K.rng.integers(-2**31, 2**31, size=(3, 631), dtype=np.int64).astype(np.int32)
+    x[0, :3] = [2**31 - 1, -2**31, 2**19]
+    ext = eng.bootstrap(2**29, x, with_keyswitch=False)
+    assert ext.shape == (3, 2049) and np.array_equal(ext, K.oracle.bootstrap(2**29, x, with_keyswitch=False, nthreads=3))
+    # the reference's stored spectra load to the same engine state
+    e2 = tfhe.Engine(K.params, 0)
+    e2.load_bootstrap_key_spectra(K.oracle.bk_spectra())
+    e2.load_keyswitch_key(K.ck.keyswitch_key)
+    assert np.array_equal(e2.bootstrap(2**29, x, with_keyswitch=False), ext)
+    e2.close()
+    K.ck.close()

@@ -180,3 +180,21 @@ def test_truth_table_mask_size_2(orc, tfhe):
     assert list(tfhe.decrypt(K.sk, out)) == [bool(y if x else z) for x, y, z in combos]
     out = K.oracle.gates(np.full(8, orc.OPS["NAND"], np.uint8), *ins, nthreads=8)
     assert list(tfhe.decrypt(K.sk, out)) == [not (x and y) for x, y, z in combos]
+
+
+def synthetic_2048(tfhe, n=630):
+    """BASELINE config 4b: SchemeParameters(630, 2^-15, 2048, 1, 3, 7, 2^-25, 8, 2, 2^-15, 1) — synthetic (the
+    reference ships no N = 2048 set; SchemeParameters is an unvalidated positional struct, api.jl:4-21)."""
+    return tfhe.SchemeParameters(n, 1 / 2**15, 2048, 1, 3, 7, 1 / 2**25, 8, 2, 1 / 2**15, 1)
+
+
+def test_truth_table_synthetic_n2048(orc, tfhe):
+    from conftest import KeySet
+    K = KeySet(tfhe, orc, synthetic_2048(tfhe, n=96), seed=2048)
+    combos = list(itertools.product((False, True), repeat=3))
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    out = K.oracle.gates(np.full(8, orc.OPS["MUX"], np.uint8), *ins, nthreads=8)
+    assert list(tfhe.decrypt(K.sk, out)) == [bool(y if x else z) for x, y, z in combos]
+    assert K.oracle.last_margin < 0.25
+    one = K.oracle.gates(np.array([orc.OPS["NAND"]], np.uint8), ins[0][:1], ins[1][:1])
+    assert np.array_equal(one, K.oracle.gates(np.array([orc.OPS["NAND"]], np.uint8), ins[0][:1], ins[1][:1], mode=orc.MODE_EXACT))

@@ -643,6 +643,230 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
 }
 
+// ---- N = 2048: two waves per blind rotation ----------------------------------------------------------
+// M = 1024 folded points.  One radix-2 DIF stage is split across the two waves of a 128-thread block:
+//   a_j = z_j + z_{j+512}  -> wave 0 -> even frequencies,   b_j = (z_j - z_{j+512}) W_1024^j -> wave 1 -> odd,
+// then each wave runs the same 512-point transform as the N = 1024 kernels on its half, MACs its own
+// frequencies, inverse-transforms them, and the halves are recombined through LDS (2 barriers per inverse
+// transform).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
+//   wave 0 pass-A input  x_r = e^{-i pi r/32}  (u + kappa u'),   lane factor w^t             in tw1f
+//   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
+// Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
+constexpr int kN2 = 2048;
+
+__host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
+{
+    constexpr double T[17] = {1.0, 0.99518472667219692873, 0.98078528040323043058, 0.95694033573220882438,
+                              0.92387953251128673848, 0.88192126434835504956, 0.83146961230254523567,
+                              0.77301045336273699338, 0.70710678118654752440, 0.63439328416364548779,
+                              0.55557023301960228867, 0.47139673682599780857, 0.38268343236508983729,
+                              0.29028467725446233105, 0.19509032201612833135, 0.09801714032956077016, 0.0};
+    const int m = ((k % 64) + 64) % 64;
+    return m <= 16 ? T[m] : m <= 32 ? -T[32 - m] : m <= 48 ? -T[m - 32] : T[64 - m];
+}
+__host__ __device__ constexpr double sin_pi32(int k) { return cos_pi32(k - 16); }
+
+struct Br2048Args {
+    const int32_t *bara;   // [R][n+1]
+    const cplx *bk;        // [n][L][2][2][2 (wave)][8][64]
+    int32_t *ext;          // [R][N+1]
+    const cplx *tw1f2;     // [2 (wave)][8][64]
+    const cplx *tw2;       // [8][8]
+    Gadget g;
+    int32_t n, mu;
+};
+
+// pass-A input from the four coefficient classes of point jj = t + 64 r (values already converted to double)
+//   u = lo - i hi (coefficients jj, jj+1024), u' = lo2 - i hi2 (jj+512, jj+1536); sg = +sqrt(1/2) (wave 0) / -sqrt(1/2)
+template <int R>
+__device__ __forceinline__ cplx fwd_in_2048(double lo, double hi, double s2, double d2, double sg, bool wave1)
+{
+    // u +- kappa u' = (lo +- (lo2-hi2)/sqrt2) - i (hi +- (lo2+hi2)/sqrt2),  s2 = lo2-hi2, d2 = lo2+hi2
+    const double re = lo + sg * s2, im = hi + sg * d2;
+    if (R == 0) return mk(re, -im);
+    const double cr = wave1 ? cos_pi32(5 * R) : cos_pi32(R), sr = wave1 ? sin_pi32(5 * R) : sin_pi32(R);
+    return mk(re * cr - im * sr, -(re * sr + im * cr));          // (re - i im) e^{-i theta}
+}
+
+template <int MM>
+__device__ __forceinline__ void rotate_sub_2048(int lane, int a, const int32_t *acc_lds, int32_t offset, int32_t xormask, int32_t (&temp)[32])
+{
+    const int base = (lane - a) & (2 * kN2 - 1);
+#pragma unroll
+    for (int m = 0; m < 32; m++) {
+        const int idx = (base + 64 * m) & (2 * kN2 - 1);
+        const int32_t v = acc_lds[idx & (kN2 - 1)];
+        const int32_t cur = acc_lds[lane + 64 * m];
+        const uint32_t sgn = (idx & kN2) ? 0xFFFFFFFFu : 0u;
+        temp[m] = (int32_t)(((((uint32_t)v ^ sgn) - sgn) - (uint32_t)cur + (uint32_t)offset) ^ (uint32_t)xormask);
+    }
+}
+
+// forward 512-point transform of this wave's half (after the radix-2 split), x in / spectrum out
+__device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+}
+
+template <int L>
+__global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P)
+{
+    constexpr int K1 = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                         // [K1][2048]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN2 * 4);                // [2 waves][kXchElems]
+    cplx *tw2_lds = xch_all + 2 * kXchElems;                                      // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave1 = (tid >> 6) != 0;                                           // wave-uniform
+    cplx *xch = xch_all + (wave1 ? kXchElems : 0);
+    cplx *xch_other = xch_all + (wave1 ? 0 : kXchElems);
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+    const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1 ? 512 : 0) + q * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = P.tw2[tid];
+    {
+        const int barb = bara[P.n] & (2 * kN2 - 1);
+        for (int j = tid; j < kN2; j += 128) {
+            const int idx = (j + barb) & (2 * kN2 - 1);
+            acc_lds[j] = 0;
+            acc_lds[kN2 + j] = (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN2 - 1);
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;
+        cplx out[K1][8];
+#pragma unroll
+        for (int d = 0; d < K1; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll 1
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[32];
+            {
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub_2048<0>(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+#define FWD_IN(R)                                                                                          \
+    {                                                                                                      \
+        const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);            \
+        const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);      \
+        x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);    \
+    }
+                FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
+#undef FWD_IN
+                fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
+#pragma unroll
+                for (int co = 0; co < K1; co++) {
+                    cplx kv[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)co * 2 * kM + k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
+                }
+            }
+        }
+        __syncthreads();   // every rotated read of this step is done before anybody updates acc_lds
+#pragma unroll
+        for (int d = 0; d < K1; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);          // alpha (wave 0) / beta (wave 1)
+#pragma unroll
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[d][r];
+            __syncthreads();
+            cplx oth[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+            __syncthreads();
+            // wave 0: (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024
+            // wave 1: (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
+#define COMBINE(R)                                                                                         \
+    {                                                                                                      \
+        const cplx al = wave1 ? oth[R] : out[d][R], be = wave1 ? out[d][R] : oth[R];                       \
+        const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);           /* e_r = e^{-i pi r/8} */      \
+        const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er; /* conj(beta) e_r: re, im */  \
+        const double vr = wave1 ? al.x - br : al.x + br;                     /* conj(alpha) = (al.x, -al.y) */ \
+        const double vi = wave1 ? -al.y - bi : -al.y + bi;                                                 \
+        const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R); \
+        const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;                                       \
+        const int jlo = lane + 64 * R + (wave1 ? 512 : 0);                                                 \
+        int32_t *ap = acc_lds + d * kN2;                                                                   \
+        ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));                           \
+        ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));             \
+    }
+            COMBINE(0) COMBINE(1) COMBINE(2) COMBINE(3) COMBINE(4) COMBINE(5) COMBINE(6) COMBINE(7)
+#undef COMBINE
+        }
+        __syncthreads();
+    }
+
+    int32_t *ext = P.ext + w * (kN2 + 1);
+    for (int j = tid; j < kN2; j += 128) {
+        const int32_t v = acc_lds[j];
+        if (j == 0) ext[0] = v;
+        else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (tid == 0) ext[kN2] = acc_lds[kN2];
+}
+
+// key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024
+__global__ __launch_bounds__(128) void bk_prepare_kernel_n2048(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out,
+                                                             const cplx *__restrict__ tw1f2, const cplx *__restrict__ tw2)
+{
+    __shared__ __attribute__((aligned(16))) cplx xch_all[2 * kXchElems + 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave1 = (tid >> 6) != 0;
+    cplx *xch = xch_all + (wave1 ? kXchElems : 0);
+    cplx *tw2_lds = xch_all + 2 * kXchElems;
+    const size_t q = blockIdx.x;
+    const int32_t *poly = bk_i32 + q * kN2;
+    const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
+    cplx tw1f[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; qq++) tw1f[qq] = tw1f2[(wave1 ? 512 : 0) + qq * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = tw2[tid];
+    __syncthreads();
+    cplx x[8];
+#define FWD_IN(R)                                                                                          \
+    {                                                                                                      \
+        const double lo = (double)poly[lane + 64 * R], l2 = (double)poly[lane + 64 * R + 512];             \
+        const double hi = (double)poly[lane + 64 * R + 1024], h2 = (double)poly[lane + 64 * R + 1536];     \
+        x[R] = fwd_in_2048<R>(lo, hi, l2 - h2, l2 + h2, sg, wave1);                                        \
+    }
+    FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
+#undef FWD_IN
+    fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+    const double s = 1.0 / 1024.0;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) out[q * 2 * kM + (wave1 ? kM : 0) + k2 * 64 + lane] = mk(x[k2].x * s, x[k2].y * s);
+}
+
+// the reference's spectra for N = 2048 (natural order, 1024 values) -> engine order
+__global__ __launch_bounds__(128) void bk_permute_c128_kernel_n2048(const cplx *__restrict__ in, cplx *__restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t q = blockIdx.x;
+    const double s = 1.0 / 1024.0;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const cplx v = in[q * 2 * kM + 2 * freq_of(lane, k2) + wv];
+        out[q * 2 * kM + wv * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
+    }
+}
+
 // Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
 // (the analogue of forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
@@ -1212,8 +1436,16 @@ struct tfhe_ctx {
 
 static void build_tables(std::vector<cplx> &h)
 {
-    h.resize(kTableElems);
+    h.resize(kTableElems + 1024);
     fill_tables<long double>(h.data(), [](long double a) { return cosl(a); }, [](long double a) { return sinl(a); });
+    // N = 2048: tw1f2[w][q][t] = e^{-i pi t (1 + 4w + 8q) / 2048}
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int w = 0; w < 2; w++)
+        for (int q = 0; q < 8; q++)
+            for (int t = 0; t < 64; t++) {
+                const long double a = -pi * (long double)(t * (1 + 4 * w + 8 * q)) / 2048.0L;
+                h[kTableElems + w * 512 + q * 64 + t] = mk((double)cosl(a), (double)sinl(a));
+            }
 }
 
 static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
@@ -1243,10 +1475,12 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: parameters must be positive and N a power of two");
     if (p.bs_l * p.bs_log2_base > 32) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: bs_l * bs_log2_base > 32");
     if (p.ks_t * p.ks_log2_base > 31) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: ks_t * ks_log2_base > 31");
-    if (p.N != kN) {
-        snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d only (got %d)", kN, p.N);
+    if (p.N != kN && p.N != kN2) {
+        snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d or %d (got %d)", kN, kN2, p.N);
         return fail(TFHE_ERR_UNSUPPORTED, buf);
     }
+    if (p.N == kN2 && (p.k != 1 || p.parties != 1))
+        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: N = 2048 is supported with tlwe_mask_size 1, single key");
     if (p.k != 1 && p.k != 2) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 or 2");
     if (p.k != 1 && p.parties != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key needs tlwe_mask_size 1 (as the reference, mk_internals.jl:89-91)");
     if (p.bs_l > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 unsupported");
@@ -1323,13 +1557,19 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_bootstrap_key: context is multi-key, use tfhe_mk_load_*");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npolys = bk_poly_count(c->P);
+    const bool big = (c->P.N == kN2);
     if (c->d_bk) { (void)hipFree(c->d_bk); c->d_bk = nullptr; c->have_bk = false; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_bk, npolys * kM * sizeof(cplx)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_bk, npolys * (size_t)(c->P.N / 2) * sizeof(cplx)));
     void *d_in = nullptr;
     HIP_TRY(c, hipMalloc(&d_in, bytes_in));
     hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        if (is_c128)
+        if (big && is_c128)
+            hipLaunchKernelGGL(bk_permute_c128_kernel_n2048, dim3((unsigned)npolys), dim3(128), 0, c->stream, (const cplx *)d_in, c->d_bk);
+        else if (big)
+            hipLaunchKernelGGL(bk_prepare_kernel_n2048, dim3((unsigned)npolys), dim3(128), 0, c->stream, (const int32_t *)d_in, c->d_bk,
+                               (const cplx *)(c->d_tables + kTableElems), c->T.tw2);
+        else if (is_c128)
             hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_bk);
         else
             hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_bk, c->T);
@@ -1346,13 +1586,13 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
 int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return load_bk_common(c, bk, bk_poly_count(c->P) * kN * sizeof(int32_t), false);
+    return load_bk_common(c, bk, bk_poly_count(c->P) * (size_t)c->P.N * sizeof(int32_t), false);
 }
 
 int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    return load_bk_common(c, bk_spectra, bk_poly_count(c->P) * kM * sizeof(cplx), true);
+    return load_bk_common(c, bk_spectra, bk_poly_count(c->P) * (size_t)(c->P.N / 2) * sizeof(cplx), true);
 }
 
 static size_t ks_word_count(const tfhe_params &p)
@@ -1405,6 +1645,20 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.g = c->g;
     a.n = c->P.n;
     a.mu = mu;
+    if (c->P.N == kN2) {
+        Br2048Args b;
+        b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu;
+        const size_t ldsb = 2 * kN2 * 4 + (2 * kXchElems + 64) * sizeof(cplx);
+        switch (c->P.bs_l) {
+        case 1: hipLaunchKernelGGL((blind_rotate_kernel_n2048<1>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
+        case 2: hipLaunchKernelGGL((blind_rotate_kernel_n2048<2>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
+        case 3: hipLaunchKernelGGL((blind_rotate_kernel_n2048<3>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
+        case 4: hipLaunchKernelGGL((blind_rotate_kernel_n2048<4>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
+        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
     if (c->P.k == 2) {
         const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
         switch (c->P.bs_l) {
