@@ -549,6 +549,109 @@ __global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
     if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
 }
 
+// ---- small batches: two waves per blind rotation ----------------------------------------------------
+// With fewer rotations than wave slots (single gates, sequential circuits, small batches) one wave per
+// rotation leaves the chip idle and a gate takes n x (4 forward + 2 inverse transforms) of latency.
+// Here wave c (c = 0: mask polynomial, c = 1: body) owns accumulator polynomial c: it rotates and
+// decomposes only its own polynomial, runs its L forward transforms, MACs both output components, hands
+// the partial sum for the other component over through LDS (double-buffered, ONE barrier per step), adds
+// what it receives, inverse-transforms its own component and updates its own polynomial.  Same arithmetic
+// per rotation as blind_rotate_kernel_v3, about half the latency.
+template <int L>
+__global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
+{
+    constexpr int K1 = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2 waves][kXchElems]
+    cplx *xfer = xch_all + 2 * kXchElems;                                        // [2 parity][2 waves][512]
+    cplx *tw2_lds = xfer + 2 * 2 * kM;                                           // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = tid >> 6;                                                     // wave = owned polynomial
+    int32_t *acc_lds = acc_all + wv * kN;
+    cplx *xch = xch_all + wv * kXchElems;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            const int32_t body = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+            acc_lds[lane + 64 * m] = wv ? body : 0;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN - 1);
+        // key polys of transform (p, c = wv): [i][p][c][co][8][64]
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
+        cplx own[8], oth[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); oth[q] = mk(0.0, 0.0); }
+        int32_t temp[16];
+        {
+            int32_t cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
+            rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
+        }
+#pragma unroll 1
+        for (int p = 0; p < L; p++) {
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            const cplx *kp = key + (size_t)p * K1 * K1 * kM;
+            cplx kown[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) kown[k2] = kp[(size_t)wv * kM + k2 * 64];           // co = wv (issued before the FFT)
+            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            cplx koth[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) koth[k2] = kp[(size_t)(1 - wv) * kM + k2 * 64];     // co = 1 - wv
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = cfma(x[k2], kown[k2], own[k2]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) oth[k2] = cfma(x[k2], koth[k2], oth[k2]);
+        }
+        // hand the other component's partial sum over (buffer by step parity: one barrier per step)
+        cplx *mine = xfer + ((i & 1) * 2 + wv) * kM, *theirs = xfer + ((i & 1) * 2 + (1 - wv)) * kM;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) mine[k2 * 64 + lane] = oth[k2];
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], theirs[k2 * 64 + lane]);
+        fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
+        int32_t accr[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
+        untwist_add2(own, accr);
+        store_acc<2>(lane, accr, acc_lds);
+        WAVE_LDS_FENCE();
+    }
+    __syncthreads();
+    int32_t *ext = P.ext + w * (kN + 1);
+    if (wv == 0) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int j = lane + 64 * m;
+            const int32_t v = acc_all[j];
+            if (j == 0) ext[0] = v;
+            else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+        }
+    } else if (lane == 0) {
+        ext[kN] = acc_all[kN];
+    }
+}
+
 // ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
 // Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
 // 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
@@ -1205,6 +1308,8 @@ struct Ks4Args {
     int32_t n, kN, G, wtiles;
     int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
     int32_t add_b;          // 1: out[out_b] = ext b (+ MUX constant) - sum; 0 (MK party > 0): accumulate into out_b
+    int32_t kslices;        // > 1 (small batches): blockIdx.z takes kN/kslices mask words, results combined with
+                            // integer atomics into an output pre-initialised to (0, ..., 0, b) by ks3_init_kernel
 };
 
 // balanced signed byte `plane` of a 32-bit word: value == sum_p sbyte(value, p) * 256^p (mod 2^32)
@@ -1278,7 +1383,11 @@ __global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
 #pragma unroll
     for (int pl = 0; pl < 4; pl++) bcur[pl] = bp[pl * 64];
 
-    for (int i4 = 0; i4 < P.kN; i4 += 4) {
+    const int i_begin = (int)blockIdx.z * (P.kN / P.kslices), i_end = i_begin + P.kN / P.kslices;
+    bp += (size_t)i_begin * bstep;
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) bcur[pl] = bp[pl * 64];
+    for (int i4 = i_begin; i4 < i_end; i4 += 4) {
         // 4 consecutive mask words of this lane's samples (MUX: sum of two extracted samples, gates.jl:174)
         uint32_t a4[MT][4];
 #pragma unroll
@@ -1292,7 +1401,7 @@ __global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             const int i = i4 + ii;
-            const i32x4 *bn = bp + (size_t)(i + 1 < P.kN ? i + 1 : i) * bstep;
+            const i32x4 *bn = bp + (size_t)((i + 1 < i_end ? i + 1 : i) - i_begin) * bstep;
 #pragma unroll
             for (int pl = 0; pl < 4; pl++) bnxt[pl] = bn[pl * 64];
             i32x4 afrag[MT];
@@ -1327,7 +1436,9 @@ __global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
                            ((uint32_t)acc[mt][3][r] << 24);
             const size_t og = P.dst ? (size_t)P.dst[gg] : (size_t)gg;
             int32_t *o = P.out + og * P.out_stride;
-            if (w < P.n) {
+            if (P.kslices > 1) {                                             // partial sum of one slice
+                atomicAdd(reinterpret_cast<unsigned int *>(o + (w < P.n ? P.out_off + w : P.out_b)), 0u - sum);
+            } else if (w < P.n) {
                 o[P.out_off + w] = (int32_t)(0u - sum);
             } else {                                                         // the b word
                 if (P.add_b) {
@@ -1389,6 +1500,7 @@ struct tfhe_ctx {
     bool timing_valid = false;
     int64_t last_rotations = 0;
     int ks_variant = 4;          // 1 = one workgroup per sample, 2 = gate-tiled, 3 = tiled + sliced + XCD-aware, 4 = int8 MFMA (default)
+    int64_t br_small = 512;      // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never)
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
     // tables
@@ -1671,6 +1783,18 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
     }
+    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2) {
+        const size_t ldsw = 2 * kN * 4 + (2 * kXchElems + 4 * kM + 64) * sizeof(cplx);
+        switch (c->P.bs_l) {
+        case 1: hipLaunchKernelGGL((blind_rotate_kernel_w2<1>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
+        case 2: hipLaunchKernelGGL((blind_rotate_kernel_w2<2>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
+        case 3: hipLaunchKernelGGL((blind_rotate_kernel_w2<3>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
+        case 4: hipLaunchKernelGGL((blind_rotate_kernel_w2<4>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
+        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
     if (c->br_variant >= 2) {
         const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
 #define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK>), dim3((unsigned)R), dim3(64), lds3, s, a)
@@ -1713,7 +1837,14 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
         a4.ext = ext; a4.bmat = (const i32x4 *)c->d_ks4; a4.e0 = e0; a4.e1 = e1; a4.dst = dst; a4.out = out;
         a4.n = c->P.n; a4.kN = k.kN; a4.G = (int)G; a4.wtiles = c->ks4_wtiles;
         a4.in_stride = k.kN + 1; a4.in_off = 0; a4.in_b = k.kN; a4.out_stride = n1; a4.out_off = 0; a4.out_b = c->P.n; a4.add_b = 1;
-        hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((G + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
+        a4.kslices = (G <= 512 && k.kN % 64 == 0) ? 16 : 1;                 // small batches: split the mask words over 16 blocks
+        if (a4.kslices > 1) {
+            Ks3Args i3;
+            i3.ext = ext; i3.e0 = e0; i3.e1 = e1; i3.dst = dst; i3.out = out; i3.kN = k.kN; i3.n = c->P.n;
+            i3.in_stride = a4.in_stride; i3.in_b = a4.in_b; i3.out_stride = n1; i3.out_b = c->P.n;
+            hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)G), dim3(256), 0, s, i3);
+        }
+        hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((G + 255) / 256), (unsigned)c->ks4_wtiles, (unsigned)a4.kslices), dim3(256), 0, s, a4);
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
     }
@@ -2062,7 +2193,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         a4.n = n; a4.kN = kN; a4.G = (int)B; a4.wtiles = c->ks4_wtiles;
         a4.in_stride = ew; a4.in_b = NP * kN; a4.out_stride = nw; a4.out_b = NP * n;
         for (int p = 0; p < NP; p++) {
-            a4.in_off = p * kN; a4.out_off = p * n; a4.add_b = (p == 0);
+            a4.in_off = p * kN; a4.out_off = p * n; a4.add_b = (p == 0); a4.kslices = 1;
             a4.bmat = (const i32x4 *)c->d_mk_ks4 + (size_t)p * c->mk_ks4_frags;
             hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((B + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
         }
@@ -2122,6 +2253,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         c->br_variant = (int)value;
         return TFHE_OK;
     }
+    if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "ks_variant")) {
         if (value < 1 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1..4");
         c->ks_variant = (int)value;

@@ -48,6 +48,19 @@ br = e2.last_timing_ms(0)
 res["config4a_128bit_4096"] = {"gates_per_s": B / w, "blind_rotate_ms": br, "keyswitch_ms": e2.last_timing_ms(1), "rot_per_s": B / br * 1e3,
                                "frac_hbm_algorithmic": B / br * 1e3 * 30965760 / 8e12}
 ck2.close()
+# config 4b: synthetic N = 2048 (630, l = 3, beta = 7)
+p4b = tfhe.SchemeParameters(630, 1 / 2**15, 2048, 1, 3, 7, 1 / 2**25, 8, 2, 1 / 2**15, 1)
+sk3, ck3 = tfhe.make_key_pair(rng, p4b)
+e3 = ck3.engine(0)
+bx3, by3 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+x, y = tfhe.encrypt(rng, sk3, bx3).data, tfhe.encrypt(rng, sk3, by3).data
+w = timed(lambda: e3.gates(ops, x, y), 3)
+out3 = e3.gates(ops, x, y)
+br = e3.last_timing_ms(0)
+res["config4b_synthetic_n2048_4096"] = {"gates_per_s": B / w, "blind_rotate_ms": br, "keyswitch_ms": e3.last_timing_ms(1), "rot_per_s": B / br * 1e3,
+                                        "frac_hbm_algorithmic": B / br * 1e3 * 61931520 / 8e12,
+                                        "decrypt_ok_fraction": float((tfhe.decrypt(sk3, out3) == ~(bx3 & by3)).mean())}
+ck3.close()
 # config 5: 2-party MK NAND x 1024
 p = tfhe.mktfhe_parameters_2party
 mrng = np.random.default_rng(321)
