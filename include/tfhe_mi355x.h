@@ -131,6 +131,22 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_
                              const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, int64_t B,
                              void *stream);
 
+/* ---- levelised circuits on device-resident ciphertexts ----------------------------------------------
+ * The caller side of the path (examples/tutorial.jl:42-62 is a 16-deep XNOR->MUX chain followed by 16
+ * parallel MUXes): ciphertexts stay in a device-resident table of `num_wires` LWE samples and each call
+ * runs ONE level of independent gates addressed by wire index, so nothing crosses PCIe between levels. */
+
+/* (Re)allocates the context's wire table: int32 [num_wires][n+1] on the device (0 frees it). */
+int32_t tfhe_wires_alloc(tfhe_ctx *ctx, int64_t num_wires);
+/* Copies `count` samples (host int32 [count][n+1]) into / out of wires [first, first+count). */
+int32_t tfhe_wires_upload(tfhe_ctx *ctx, int64_t first, int64_t count, const int32_t *host);
+int32_t tfhe_wires_download(tfhe_ctx *ctx, int64_t first, int64_t count, int32_t *host);
+/* wire[out[g]] = gate_<opcode[g]>(ck, wire[a[g]], wire[b[g]], wire[c[g]]) for g < B (host index arrays; b / c
+ * may be NULL if no opcode reads them).  A level must not read a wire it writes, nor write a wire twice
+ * (TFHE_ERR_INVALID_ARG).  Asynchronous on the context's stream; ordered with later calls. */
+int32_t tfhe_gates_level(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *a, const int32_t *b,
+                         const int32_t *c, const int32_t *out, int64_t B);
+
 /* bootstrap(bk, ks, mu, x) (bootstrap.jl:92-95) if with_keyswitch != 0, else
  * bootstrap_wo_keyswitch(bk, mu, x) (bootstrap.jl:69-82).
  * in: host int32 [B][n+1]; out: host int32 [B][n+1] or [B][k*N+1]. */

@@ -1,0 +1,61 @@
+"""Levelised circuit execution: host-side levelisation on CPU; on the GPU the tutorial circuit
+(examples/tutorial.jl) run level by level on the device-resident wire table, checked word for word against the
+oracle evaluating the same gates one at a time."""
+import numpy as np
+import pytest
+
+
+def tutorial_min_circuit(tfhe, nbits=16):
+    """examples/tutorial.jl:42-62: carry = MUX(XNOR(a_i, b_i), carry, a_i) over the bits, then out_i = MUX(carry, b_i, a_i)."""
+    c = tfhe.Circuit()
+    a, b = c.inputs(nbits), c.inputs(nbits)
+    carry = c.constant(False)
+    for i in range(nbits):
+        carry = c.mux(c.xnor(a[i], b[i]), carry, a[i])
+    c.set_outputs([c.mux(carry, b[i], a[i]) for i in range(nbits)])
+    return c
+
+
+def test_levelisation(tfhe):
+    c = tutorial_min_circuit(tfhe, 16)
+    lv = c.levels()
+    # level 1: the constant and the 16 XNORs (all independent); then a 16-deep MUX chain; then 16 parallel MUXes
+    assert len(lv) == 18
+    assert len(lv[0]) == 17 and all(len(l) == 1 for l in lv[1:17]) and len(lv[17]) == 16
+    assert c.num_wires == 32 + 1 + 16 + 16 + 16
+    for ops, a, b, cc, out in c.level_arrays():
+        assert ops.dtype == np.uint8 and a.shape == b.shape == cc.shape == out.shape == ops.shape
+        assert not (set(out.tolist()) & (set(a.tolist()) | set(b.tolist()) | set(cc.tolist())))
+    with pytest.raises(ValueError):
+        c.gate("NAND", 0)           # wrong arity
+    with pytest.raises(ValueError):
+        c.gate("NAND", 0, 10**6)    # unknown wire
+
+
+def _oracle_eval(circuit, oracle_obj, orc, inputs):
+    wires = [row for row in inputs]
+    for name, a, b, cc in circuit._gates:
+        ops = np.array([orc.OPS[name]], np.uint8)
+        z = np.zeros((1, inputs.shape[1]), np.int32)
+        x = wires[a][None] if a >= 0 else z
+        y = wires[b][None] if b >= 0 else z
+        w = wires[cc][None] if cc >= 0 else z
+        wires.append(oracle_obj.gates(ops, x, y, w)[0])
+    return np.stack([wires[w] for w in circuit._outputs])
+
+
+@pytest.mark.gpu
+def test_tutorial_circuit_on_device(tfhe, orc, keys80):
+    K = keys80
+    c = tutorial_min_circuit(tfhe, 16)
+    bits = [(2017 >> i) & 1 == 1 for i in range(16)] + [(42 >> i) & 1 == 1 for i in range(16)]
+    enc = tfhe.encrypt(K.rng, K.sk, bits)
+    res = c.run(K.ck, enc)
+    assert sum(int(v) << i for i, v in enumerate(tfhe.decrypt(K.sk, res))) == 42     # "Answer: 42"
+    assert np.array_equal(res.data, _oracle_eval(c, K.oracle, orc, enc.data))
+    # error paths of the level API
+    eng = K.ck.engine(0)
+    with pytest.raises(tfhe.EngineError):   # reads a wire written in the same level
+        eng.gates_level(np.array([0, 0], np.uint8), np.array([0, 40], np.int32), np.array([1, 1], np.int32), None, np.array([40, 41], np.int32))
+    with pytest.raises(tfhe.EngineError):   # out of range
+        eng.gates_level(np.array([0], np.uint8), np.array([0], np.int32), np.array([10**6], np.int32), None, np.array([40], np.int32))

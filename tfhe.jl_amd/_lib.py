@@ -17,6 +17,7 @@ ABI_SYMBOLS = [
     "tfhe_load_keyswitch_key", "tfhe_gates_batch", "tfhe_gates_batch_dev", "tfhe_bootstrap_batch",
     "tfhe_keyswitch_batch", "tfhe_mk_load_bootstrap_key_i32", "tfhe_mk_load_keyswitch_key",
     "tfhe_mk_gate_nand_batch", "tfhe_last_timing_ms", "tfhe_last_rotation_count", "tfhe_set_option",
+    "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
 ]
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
@@ -70,6 +71,10 @@ def load():
     lib.tfhe_last_rotation_count.argtypes = [vp]
     lib.tfhe_last_rotation_count.restype = i64
     lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.tfhe_wires_alloc.argtypes = [vp, i64]
+    lib.tfhe_wires_upload.argtypes = [vp, i64, i64, vp]
+    lib.tfhe_wires_download.argtypes = [vp, i64, i64, vp]
+    lib.tfhe_gates_level.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     _lib = lib
     return lib
 
@@ -173,6 +178,30 @@ class Engine:
         out = np.empty((B, self.n + 1), np.int32)
         self._check(self._lib.tfhe_keyswitch_batch(self._h, _ptr(x), _ptr(out), B))
         return out
+
+    # ---- levelised circuits on the device-resident wire table ----
+    def wires_alloc(self, num_wires):
+        self._check(self._lib.tfhe_wires_alloc(self._h, int(num_wires)))
+
+    def wires_upload(self, first, samples):
+        m = _i32c(samples)
+        if m.ndim != 2 or m.shape[1] != self.n + 1:
+            raise ValueError("samples must be [count][n+1]")
+        self._check(self._lib.tfhe_wires_upload(self._h, int(first), m.shape[0], _ptr(m)))
+
+    def wires_download(self, first, count):
+        out = np.empty((int(count), self.n + 1), np.int32)
+        self._check(self._lib.tfhe_wires_download(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def gates_level(self, opcodes, a, b, c, out):
+        ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
+        arrs = [None if v is None else _i32c(v) for v in (a, b, c, out)]
+        for v in arrs:
+            if v is not None and v.shape != (ops.size,):
+                raise ValueError("index arrays must have one entry per gate")
+        self._check(self._lib.tfhe_gates_level(self._h, _ptr(ops), _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]),
+                                               _ptr(arrs[3]), ops.size))
 
     # ---- multi-key ----
     def mk_load_bootstrap_key(self, bk_i32, parties):

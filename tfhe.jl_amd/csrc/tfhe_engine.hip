@@ -54,17 +54,17 @@ __host__ __device__ inline GateForm gate_form(int kind)
     }
 }
 
-// rot_gate[w] = gate index, rot_kind[w] = kind (see gate_form); writes bara[w][0..n] (barb last).
-__global__ void prologue_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ in1,
-                                const int32_t *__restrict__ in2, const int32_t *__restrict__ rot_gate,
+// rot_a[w] / rot_b[w] = rows of the two operands of rotation w (batch mode: the gate index; level mode: wire
+// indices), rot_kind[w] = kind (see gate_form); writes bara[w][0..n] (barb last).
+__global__ void prologue_kernel(const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                const int32_t *__restrict__ rot_a, const int32_t *__restrict__ rot_b,
                                 const uint8_t *__restrict__ rot_kind, int32_t *__restrict__ bara, int n,
                                 int log2_2N)
 {
     const int w = blockIdx.x;
-    const size_t g = (size_t)rot_gate[w];
     const GateForm f = gate_form(rot_kind[w]);
-    const int32_t *x = in0 + g * (n + 1);
-    const int32_t *y = (f.use_z ? in2 : in1) + g * (n + 1);
+    const int32_t *x = in0 + (size_t)rot_a[w] * (n + 1);
+    const int32_t *y = (f.use_z ? in2 : in1) + (size_t)rot_b[w] * (n + 1);
     for (int i = threadIdx.x; i <= n; i += blockDim.x) {
         uint32_t v;
         if (f.mul2) {
@@ -1454,17 +1454,18 @@ __global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
 }
 
 // gate_not / gate_constant / copy (gates.jl:76-93)
-__global__ void trivial_gates_kernel(const int32_t *__restrict__ in0, const int32_t *__restrict__ gates,
-                                     const uint8_t *__restrict__ ops, int32_t *__restrict__ out, int n)
+__global__ void trivial_gates_kernel(const int32_t *in0, const int32_t *__restrict__ src_rows,
+                                     const int32_t *__restrict__ dst_rows, const uint8_t *__restrict__ ops,
+                                     int32_t *out, int n)
 {
-    const size_t g = (size_t)gates[blockIdx.x];
+    const size_t gs = (size_t)src_rows[blockIdx.x], gd = (size_t)dst_rows[blockIdx.x];
     const int op = ops[blockIdx.x];
     for (int i = threadIdx.x; i <= n; i += blockDim.x) {
         uint32_t v;
-        if (op == TFHE_GATE_NOT) v = 0u - (uint32_t)in0[g * (n + 1) + i];
-        else if (op == TFHE_GATE_COPY) v = (uint32_t)in0[g * (n + 1) + i];
+        if (op == TFHE_GATE_NOT) v = 0u - (uint32_t)in0[gs * (n + 1) + i];
+        else if (op == TFHE_GATE_COPY) v = (uint32_t)in0[gs * (n + 1) + i];
         else v = (i == n) ? (op == TFHE_GATE_CONST1 ? (1u << 29) : 0u - (1u << 29)) : 0u;
-        out[g * (n + 1) + i] = (int32_t)v;
+        out[gd * (n + 1) + i] = (int32_t)v;
     }
 }
 
@@ -1521,6 +1522,9 @@ struct tfhe_ctx {
     size_t mk_ksp_words = 0;       // words per party in d_mk_ksp
     int mk_parties = 0;
     bool have_mk_bk = false, have_mk_ks = false;
+
+    // device-resident wire table for levelised circuits: int32 [num_wires][n+1]
+    int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
     DevBuf bara, ext, map, io[4];
@@ -1641,6 +1645,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_ks) (void)hipFree(c->d_ks);
     if (c->d_ksp) (void)hipFree(c->d_ksp);
     if (c->d_ks4) (void)hipFree(c->d_ks4);
+    if (c->d_wires) (void)hipFree(c->d_wires);
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
@@ -1887,53 +1892,51 @@ static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
     return TFHE_OK;
 }
 
-int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *d_in0, const int32_t *d_in1,
-                             const int32_t *d_in2, int32_t *d_out, int64_t B, void *stream)
+// Common body of tfhe_gates_batch_dev (operands = rows g of three arrays, ia = ib = ic = io = NULL) and
+// tfhe_gates_level (operands = rows ia[g], ib[g], ic[g] of one wire table, result row io[g]).
+static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, int64_t B, const int32_t *d_in0,
+                         const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, const int32_t *ia, const int32_t *ib,
+                         const int32_t *ic, const int32_t *io, hipStream_t s)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (B < 0 || (B > 0 && (!opcodes || !d_out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
-    if (B == 0) { c->timing_valid = false; c->last_rotations = 0; return TFHE_OK; }
-    if (B > (int64_t)1 << 30) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: B too large");
-    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_batch: context is multi-key");
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-
     // classify gates: rotations (R), keyswitches (G), trivial (T)
     size_t R = 0, G = 0, Tn = 0;
     bool need1 = false, need2 = false, need0 = false;
     for (int64_t g = 0; g < B; g++) {
         const int op = opcodes[g];
-        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: bad opcode %d at gate %lld", op, (long long)g);
+        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "%s: bad opcode %d at gate %lld", who, op, (long long)g);
         if (op == TFHE_GATE_MUX) { R += 2; G += 1; need0 = need1 = need2 = true; }
         else if (op == TFHE_GATE_NOT || op == TFHE_GATE_COPY) { Tn++; need0 = true; }
         else if (op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1) { Tn++; }
         else { R += 1; G += 1; need0 = need1 = true; }
     }
     if ((need0 && !d_in0) || (need1 && !d_in1) || (need2 && !d_in2))
-        return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: an operand array required by the opcodes is NULL");
-    if (R > 0 && (!c->have_bk || !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "gates_batch: bootstrapping/keyswitch key not loaded");
+        return c->set_err(TFHE_ERR_INVALID_ARG, "%s: an operand array required by the opcodes is NULL", who);
+    if (R > 0 && (!c->have_bk || !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "%s: bootstrapping/keyswitch key not loaded", who);
 
-    // index maps, one pinned staging block: rot_gate[R] | ks_e0[G] | ks_e1[G] | ks_dst[G] | triv_gate[T] | rot_kind[R] | triv_op[T]
-    const size_t map_bytes = (R + 3 * G + Tn) * 4 + R + Tn;
+    // index maps, one pinned staging block:
+    //   rot_a[R] | rot_b[R] | ks_e0[G] | ks_e1[G] | ks_dst[G] | triv_src[T] | triv_dst[T] | rot_kind[R] | triv_op[T]
+    const size_t map_bytes = (2 * R + 3 * G + 2 * Tn) * 4 + R + Tn;
     int32_t rc = ensure_host_map(c, map_bytes);
     if (rc) return rc;
-    int32_t *h_rot_gate = (int32_t *)c->h_map;
-    int32_t *h_e0 = h_rot_gate + R, *h_e1 = h_e0 + G, *h_dst = h_e1 + G, *h_triv = h_dst + G;
-    uint8_t *h_kind = (uint8_t *)(h_triv + Tn), *h_top = h_kind + R;
+    int32_t *h_ra = (int32_t *)c->h_map, *h_rb = h_ra + R;
+    int32_t *h_e0 = h_rb + R, *h_e1 = h_e0 + G, *h_dst = h_e1 + G, *h_ts = h_dst + G, *h_td = h_ts + Tn;
+    uint8_t *h_kind = (uint8_t *)(h_td + Tn), *h_top = h_kind + R;
     {
         size_t r = 0, k = 0, t = 0;
         for (int64_t g = 0; g < B; g++) {
             const int op = opcodes[g];
+            const int32_t ra = ia ? ia[g] : (int32_t)g, rb = ib ? ib[g] : (int32_t)g, rcw = ic ? ic[g] : (int32_t)g;
+            const int32_t ro = io ? io[g] : (int32_t)g;
             if (op == TFHE_GATE_MUX) {
-                h_rot_gate[r] = (int32_t)g; h_kind[r] = 100;
-                h_rot_gate[r + 1] = (int32_t)g; h_kind[r + 1] = 101;
-                h_e0[k] = (int32_t)r; h_e1[k] = (int32_t)(r + 1); h_dst[k] = (int32_t)g;
+                h_ra[r] = ra; h_rb[r] = rb; h_kind[r] = 100;           // AND(x, y)      gates.jl:166
+                h_ra[r + 1] = ra; h_rb[r + 1] = rcw; h_kind[r + 1] = 101;   // AND(NOT x, z)  gates.jl:170
+                h_e0[k] = (int32_t)r; h_e1[k] = (int32_t)(r + 1); h_dst[k] = ro;
                 r += 2; k++;
             } else if (op == TFHE_GATE_NOT || op == TFHE_GATE_COPY || op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1) {
-                h_triv[t] = (int32_t)g; h_top[t] = (uint8_t)op; t++;
+                h_ts[t] = ra; h_td[t] = ro; h_top[t] = (uint8_t)op; t++;
             } else {
-                h_rot_gate[r] = (int32_t)g; h_kind[r] = (uint8_t)op;
-                h_e0[k] = (int32_t)r; h_e1[k] = -1; h_dst[k] = (int32_t)g;
+                h_ra[r] = ra; h_rb[r] = rb; h_kind[r] = (uint8_t)op;
+                h_e0[k] = (int32_t)r; h_e1[k] = -1; h_dst[k] = ro;
                 r++; k++;
             }
         }
@@ -1942,16 +1945,16 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t 
     HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, map_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipEventRecord(c->map_ev, s));
     c->map_pending = true;
-    const int32_t *d_rot_gate = (const int32_t *)c->map.p;
-    const int32_t *d_e0 = d_rot_gate + R, *d_e1 = d_e0 + G, *d_dst = d_e1 + G, *d_triv = d_dst + G;
-    const uint8_t *d_kind = (const uint8_t *)(d_triv + Tn), *d_top = d_kind + R;
+    const int32_t *d_ra = (const int32_t *)c->map.p, *d_rb = d_ra + R;
+    const int32_t *d_e0 = d_rb + R, *d_e1 = d_e0 + G, *d_dst = d_e1 + G, *d_ts = d_dst + G, *d_td = d_ts + Tn;
+    const uint8_t *d_kind = (const uint8_t *)(d_td + Tn), *d_top = d_kind + R;
 
     const int n = c->P.n, kNn = c->P.k * c->P.N;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     if (R > 0) {
         HIP_TRY(c, c->bara.reserve(R * (size_t)(n + 1) * 4));
         HIP_TRY(c, c->ext.reserve(R * (size_t)(kNn + 1) * 4));
-        hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)R), dim3(256), 0, s, d_in0, d_in1, d_in2, d_rot_gate, d_kind,
+        hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)R), dim3(256), 0, s, d_in0, d_in1, d_in2, d_ra, d_rb, d_kind,
                            (int32_t *)c->bara.p, n, ilog2i(2 * c->P.N));
         HIP_TRY(c, hipGetLastError());
     }
@@ -1967,12 +1970,116 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t 
     }
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (Tn > 0) {
-        hipLaunchKernelGGL(trivial_gates_kernel, dim3((unsigned)Tn), dim3(256), 0, s, d_in0, d_triv, d_top, d_out, n);
+        hipLaunchKernelGGL(trivial_gates_kernel, dim3((unsigned)Tn), dim3(256), 0, s, d_in0, d_ts, d_td, d_top, d_out, n);
         HIP_TRY(c, hipGetLastError());
     }
     c->timing_valid = true;
     c->last_rotations = (int64_t)R;
     return TFHE_OK;
+}
+
+int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *d_in0, const int32_t *d_in1,
+                             const int32_t *d_in2, int32_t *d_out, int64_t B, void *stream)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!opcodes || !d_out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
+    if (B == 0) { c->timing_valid = false; c->last_rotations = 0; return TFHE_OK; }
+    if (B > (int64_t)1 << 30) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: B too large");
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_batch: context is multi-key");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_gates(c, "gates_batch", opcodes, B, d_in0, d_in1, d_in2, d_out, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+// ---- levelised circuit execution on a device-resident wire table -------------------------
+int32_t tfhe_wires_alloc(tfhe_ctx *c, int64_t num_wires)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (num_wires < 0 || num_wires > ((int64_t)1 << 30)) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_alloc: bad wire count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_wires) { (void)hipFree(c->d_wires); c->d_wires = nullptr; c->num_wires = 0; }
+    if (num_wires == 0) return TFHE_OK;
+    HIP_TRY(c, hipMalloc((void **)&c->d_wires, (size_t)num_wires * (c->P.n + 1) * 4));
+    c->num_wires = num_wires;
+    return TFHE_OK;
+}
+
+static int32_t wires_range_ok(tfhe_ctx *c, const char *who, int64_t first, int64_t count, const void *host)
+{
+    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "%s: no wire table allocated", who);
+    if (first < 0 || count < 0 || first + count > c->num_wires || (count > 0 && !host))
+        return c->set_err(TFHE_ERR_INVALID_ARG, "%s: wire range [%lld, %lld) outside the table of %lld wires or NULL buffer", who,
+                          (long long)first, (long long)(first + count), (long long)c->num_wires);
+    return TFHE_OK;
+}
+
+int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32_t *host)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    int32_t rc = wires_range_ok(c, "wires_upload", first, count, host);
+    if (rc || count == 0) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t row = (size_t)(c->P.n + 1) * 4;
+    HIP_TRY(c, hipMemcpyAsync((char *)c->d_wires + (size_t)first * row, host, (size_t)count * row, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int32_t tfhe_wires_download(tfhe_ctx *c, int64_t first, int64_t count, int32_t *host)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    int32_t rc = wires_range_ok(c, "wires_download", first, count, host);
+    if (rc || count == 0) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t row = (size_t)(c->P.n + 1) * 4;
+    HIP_TRY(c, hipMemcpyAsync(host, (const char *)c->d_wires + (size_t)first * row, (size_t)count * row, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
+                         const int32_t *out, int64_t B)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_level: context is multi-key");
+    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "gates_level: no wire table allocated");
+    // every index in range; no wire both written and read inside one level (the level's gates are independent)
+    std::vector<uint8_t> mark((size_t)c->num_wires, 0);
+    auto bad = [&](int64_t v) { return v < 0 || v >= c->num_wires; };
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: bad opcode %d at gate %lld", op, (long long)g);
+        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
+        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
+        const bool has_c = (op == TFHE_GATE_MUX);
+        if ((has_a && (!a || bad(a[g]))) || (has_b && (!b || bad(b[g]))) || (has_c && (!cc || bad(cc[g]))) || bad(out[g]))
+            return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: wire index out of range (or missing operand array) at gate %lld", (long long)g);
+        if (mark[(size_t)out[g]] & 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: wire %d written twice in one level", out[g]);
+        mark[(size_t)out[g]] |= 1;
+    }
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
+        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
+        if ((has_a && (mark[(size_t)a[g]] & 1)) || (has_b && (mark[(size_t)b[g]] & 1)) || (op == TFHE_GATE_MUX && (mark[(size_t)cc[g]] & 1)))
+            return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: gate %lld reads a wire written in the same level", (long long)g);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    // operands of opcodes that ignore them get a valid dummy row (0)
+    std::vector<int32_t> ia((size_t)B), ib((size_t)B), ic((size_t)B);
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
+        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
+        ia[(size_t)g] = has_a ? a[g] : 0;
+        ib[(size_t)g] = has_b ? b[g] : 0;
+        ic[(size_t)g] = op == TFHE_GATE_MUX ? cc[g] : 0;
+    }
+    return run_gates(c, "gates_level", opcodes, B, c->d_wires, c->d_wires, c->d_wires, c->d_wires, ia.data(), ib.data(), ic.data(), out,
+                     c->stream);
 }
 
 int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
@@ -2171,7 +2278,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     // mk_gate_nand prologue (mk_gates.jl:8-10) = the NAND affine form over P*n+1 words, then mod-switch
     hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)B), dim3(256), 0, s, (const int32_t *)c->io[0].p, (const int32_t *)c->io[1].p,
-                       (const int32_t *)nullptr, d_gate, d_kind, (int32_t *)c->bara.p, NP * n, ilog2i(2 * c->P.N));
+                       (const int32_t *)nullptr, d_gate, d_gate, d_kind, (int32_t *)c->bara.p, NP * n, ilog2i(2 * c->P.N));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     MkBrArgs a;
