@@ -64,3 +64,18 @@ def test_host_keygen_shapes_and_roundtrip(tfhe, keys80):
     assert np.array_equal(tfhe.decrypt(K.sk, tfhe.encrypt(K.rng, K.sk, bits)), bits)
     s = tfhe.encrypt(K.rng, K.sk, True)
     assert isinstance(s, tfhe.LweSample) and tfhe.decrypt(K.sk, s) is True
+
+
+def test_cloud_key_file_roundtrip(tfhe, tmp_path):
+    """The engine's flat key container (the reference has no serialisation)."""
+    params = tfhe.SchemeParameters(8, 1 / 2**15, 1024, 1, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1)
+    sk, ck = tfhe.make_key_pair(np.random.default_rng(5), params)
+    path = str(tmp_path / "ck.tfhe")
+    tfhe.save_cloud_key(path, ck)
+    back = tfhe.load_cloud_key(path)
+    assert back.params == params
+    assert np.array_equal(back.bootstrap_key, ck.bootstrap_key) and np.array_equal(back.keyswitch_key, ck.keyswitch_key)
+    with open(path, "r+b") as f:
+        f.write(b"X")
+    with pytest.raises(ValueError):
+        tfhe.load_cloud_key(path)
