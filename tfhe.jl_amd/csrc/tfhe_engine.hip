@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
 //   * key spectra of the next transform prefetched into registers while the current FFT runs;
 //   * no s_barrier: wave-private LDS needs only compiler-level ordering;
 //   * no branch on bara[i] == 0 (the step then adds exactly zero).
-template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */>
+template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */>
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 {
     constexpr int K1 = 2;
@@ -238,6 +238,11 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     tw2_lds[lane] = P.T.tw2[lane];
+    cplx tw2r[8];
+    if (TW2REG) {
+#pragma unroll
+        for (int q = 1; q < 8; q++) tw2r[q] = P.T.tw2[q * 8 + (lane & 7)];
+    }
     {
         const int barb = bara[P.n] & (2 * kN - 1);
 #pragma unroll
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
             {
                 cplx t2[8];
 #pragma unroll
-                for (int q = 1; q < 8; q++) t2[q] = tw2_lds[q * 8 + (lane & 7)];
+                for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
                 dft8<false>(x);
 #pragma unroll
                 for (int q = 1; q < 8; q++) x[q] = cmul(x[q], t2[q]);
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
             {
                 cplx t2[8];
 #pragma unroll
-                for (int q = 1; q < 8; q++) t2[q] = tw2_lds[q * 8 + (lane & 7)];
+                for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
 #pragma unroll
                 for (int q = 1; q < 8; q++) out[co][q] = cmulc(out[co][q], t2[q]);
             }
@@ -1802,7 +1807,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     }
     if (c->br_variant >= 2) {
         const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-#define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK>), dim3((unsigned)R), dim3(64), lds3, s, a)
+#define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
         const bool half = (c->br_variant == 3);
         switch (c->P.bs_l) {
         case 1: if (half) LAUNCH_V3(1, 8); else LAUNCH_V3(1, 16); break;
