@@ -42,7 +42,7 @@ def test_gpu_reproduces_golden(tfhe, kat):
     assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
     # every kernel variant gives the same words (br_small = -1: one wave per rotation even for small batches;
     # default: the two-waves-per-rotation kernel takes batches this small)
-    for bv, kv, small in ((1, 1, -1), (2, 2, -1), (3, 3, -1), (2, 4, -1), (2, 4, 512)):
+    for bv, kv, small in ((1, 1, -1), (2, 3, -1), (3, 3, -1), (2, 4, -1), (2, 4, 512)):
         e.set_option("br_variant", bv)
         e.set_option("ks_variant", kv)
         e.set_option("br_small", small)

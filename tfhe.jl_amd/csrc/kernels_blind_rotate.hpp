@@ -1,0 +1,931 @@
+// kernels_blind_rotate.hpp — blind rotation + sample extraction kernels and bootstrapping-key preparation
+// (bootstrap.jl:19-82, tgsw.jl:99-129, polynomials.jl:106-132, tlwe.jl:55-59; mk_internals.jl:348-391,464-495).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/tfhe_mi355x.h"
+#include "br_core.hpp"
+
+using namespace tfhe;
+
+struct BrArgs {
+    const int32_t *bara;  // [R][n+1], barb last
+    const cplx *bk;       // [n][L][K1][K1][8][64] spectra, permuted order, scaled by 1/M
+    int32_t *ext;         // [R][(K1-1)*N + 1]
+    Tables T;
+    Gadget g;
+    int32_t n;
+    int32_t mu;
+};
+
+template <int K1>
+__device__ __forceinline__ void store_acc(int lane, const int32_t (&acc)[16], int32_t *acc_lds)
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) acc_lds[lane + 64 * m] = acc[m];
+}
+
+// One wave = one blind rotation + extraction.
+template <int L, int K1>
+__global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);            // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);        // [kXchElems]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+
+    // accum = (0, ..., 0, X^{-barb} * (mu, ..., mu))     bootstrap.jl:54-56,78 ; tlwe.jl:77-81
+    int32_t acc[K1][16];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int c = 0; c < K1 - 1; c++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) acc[c][m] = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc[K1 - 1][m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+#pragma unroll
+        for (int c = 0; c < K1; c++) store_acc<K1>(lane, acc[c], acc_lds + c * kN);
+    }
+    __syncthreads();
+
+    for (int i = 0; i < P.n; i++) {                                   // bootstrap.jl:33
+        const int a = bara[i] & (2 * kN - 1);
+        if (a == 0) continue;                                         // bootstrap.jl:34
+        const cplx *bki = P.bk + (size_t)i * (L * K1 * K1 * kM);
+        cplx out[K1][8];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
+
+#pragma unroll
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[16];
+            rotate_sub(lane, a, acc_lds + c * kN, acc[c], P.g.offset, temp);   // bootstrap.jl:21
+#pragma unroll
+            for (int p = 1; p <= L; p++) {
+                cplx x[8];
+                load_digits(lane, temp, p, P.g, P.T, x);                      // tgsw.jl:126-127
+                fwd_pass_a(lane, x, P.T);
+                x1_store_a(lane, x, xch);
+                __syncthreads();
+                x1_load_b(lane, x, xch);
+                __syncthreads();
+                fwd_pass_b(lane, x, P.T);
+                x2_store(lane, x, xch);
+                __syncthreads();
+                x2_load(lane, x, xch);
+                __syncthreads();
+                fwd_pass_c(x);
+                // out[co] += D[p, c] .* BK_i[p, c].a[co]                      tgsw.jl:128
+                const cplx *kp = bki + (size_t)((p - 1) * K1 + c) * K1 * kM + lane;
+#pragma unroll
+                for (int co = 0; co < K1; co++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kp[(co * 8 + k2) * 64], out[co][k2]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < K1; co++) {                                      // polynomials.jl:119-132
+            inv_pass_c(out[co]);
+            x2_store(lane, out[co], xch);
+            __syncthreads();
+            x2_load(lane, out[co], xch);
+            __syncthreads();
+            inv_pass_b(lane, out[co], P.T);
+            x1_store_b(lane, out[co], xch);
+            __syncthreads();
+            x1_load_a(lane, out[co], xch);
+            __syncthreads();
+            inv_pass_a(lane, out[co], P.T);
+            untwist_add(lane, out[co], P.T, acc[co]);                          // bootstrap.jl:22
+            store_acc<K1>(lane, acc[co], acc_lds + co * kN);
+        }
+        __syncthreads();
+    }
+
+    // tlwe_extract_sample (tlwe.jl:55-59): a'[0] = p[0], a'[m] = -p[N-m]; b' = body[0]
+    int32_t *ext = P.ext + w * ((K1 - 1) * kN + 1);
+#pragma unroll
+    for (int c = 0; c < K1 - 1; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int j = lane + 64 * m;
+            if (j == 0) ext[c * kN] = acc[c][m];
+            else ext[c * kN + kN - j] = (int32_t)(0u - (uint32_t)acc[c][m]);
+        }
+    if (lane == 0) ext[(K1 - 1) * kN] = acc[K1 - 1][0];
+}
+
+// Wave-private LDS hand-off: LDS instructions of one wave execute in issue order, so a compiler-level
+// fence is all a single-wave workgroup needs between a ds_write and the ds_read of another lane's data.
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+// v3: one wave per blind rotation at 2 waves/SIMD (<= 256 VGPRs, no AGPR/scratch spills).
+//   * pass-A twiddles (with the lane part of the twist folded in) resident in registers, pass-B twiddles
+//     in a 1 KB wave-private LDS table, the register part of the twist as compile-time constants:
+//     no global loads on the critical path except the key;
+//   * the accumulator lives only in LDS (read at rotate time and at the final add);
+//   * key spectra of the next transform prefetched into registers while the current FFT runs;
+//   * no s_barrier: wave-private LDS needs only compiler-level ordering;
+//   * no branch on bara[i] == 0 (the step then adds exactly zero).
+template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */>
+__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
+{
+    constexpr int K1 = 2;
+    constexpr int F = K1 * L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [kXchElems]
+    cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    cplx tw2r[8];
+    if (TW2REG) {
+#pragma unroll
+        for (int q = 1; q < 8; q++) tw2r[q] = P.T.tw2[q * 8 + (lane & 7)];
+    }
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+
+    cplx kbuf[16];
+    // chunk f of step: key spectra for transform f = (c, p): 16 values per lane (co-major, k2 minor)
+    auto key_ptr = [&](int step, int f) {
+        const int c = f / L, p = f % L;
+        return P.bk + (size_t)step * (L * K1 * K1 * kM) + (size_t)(p * K1 + c) * K1 * kM + lane;
+    };
+    {
+        const cplx *kp = key_ptr(0, 0);
+#pragma unroll
+        for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
+    }
+
+    int a_next = bara[0] & (2 * kN - 1);
+    for (int i = 0; i < P.n; i++) {
+        const int a = a_next;
+        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+
+        cplx out[K1][8];
+#pragma unroll
+        for (int c = 0; c < K1; c++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
+
+        int32_t temp[16];
+#pragma unroll 1
+        for (int f = 0; f < F; f++) {
+            const int c = f / L, p = f % L;        // component, digit index (0-based)
+            if (p == 0) {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));   // keeps the 32 rotate addresses/signs from being hoisted out of the f loop
+                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
+            }
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            // pass A
+            dft8<false>(x);
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+            x1_store_a(lane, x, xch);
+            WAVE_LDS_FENCE();
+            x1_load_b(lane, x, xch);
+            // pass B (twiddles from the LDS table)
+            {
+                cplx t2[8];
+#pragma unroll
+                for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
+                dft8<false>(x);
+#pragma unroll
+                for (int q = 1; q < 8; q++) x[q] = cmul(x[q], t2[q]);
+            }
+            WAVE_LDS_FENCE();
+            x2_store(lane, x, xch);
+            WAVE_LDS_FENCE();
+            x2_load(lane, x, xch);
+            WAVE_LDS_FENCE();
+            dft8<false>(x);
+            // MAC: out[co] += D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128)
+            if (KPF == 16) {
+#pragma unroll
+                for (int co = 0; co < K1; co++)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
+            } else {
+                const cplx *kp = key_ptr(i, f);
+                cplx k1v[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kbuf[k2], out[0][k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], k1v[k2], out[1][k2]);
+            }
+            // prefetch the next transform's key
+            {
+                const bool last = (f + 1 == F);
+                // (unconditional: on the very last transform this re-reads a valid chunk; a conditional
+                //  prefetch doubles the register pressure through the phi of old and new values)
+                const cplx *kp = last ? key_ptr(i + 1 < P.n ? i + 1 : i, 0) : key_ptr(i, f + 1);
+#pragma unroll
+                for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < K1; co++) {
+            dft8<true>(out[co]);
+            x2_store(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+            x2_load(lane, out[co], xch);
+            {
+                cplx t2[8];
+#pragma unroll
+                for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
+#pragma unroll
+                for (int q = 1; q < 8; q++) out[co][q] = cmulc(out[co][q], t2[q]);
+            }
+            dft8<true>(out[co]);
+            WAVE_LDS_FENCE();
+            x1_store_b(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+            x1_load_a(lane, out[co], xch);
+            WAVE_LDS_FENCE();
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[co][q] = cmulc(out[co][q], tw1f[q]);
+            dft8<true>(out[co]);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + lane + 64 * m];
+            untwist_add2(out[co], accr);
+            store_acc<K1>(lane, accr, acc_lds + co * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+
+    int32_t *ext = P.ext + w * (kN + 1);
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int j = lane + 64 * m;
+        const int32_t v = acc_lds[j];
+        if (j == 0) ext[0] = v;
+        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (lane == 0) ext[kN] = acc_lds[kN];
+}
+
+// ---- multi-key blind rotation (2 parties) ----------------------------------------------------------
+// mk_internals.jl:464-495 (mk_mux_rotate, mk_blind_rotate, extract) with mk_tgsw_extern_mul (:348-391).
+// Accumulator = P mask polynomials + body (P = 2): 3 polynomials in LDS.  Per step (party i, bit j):
+// 3*L forward transforms, MAC against the expanded key polys x, y, c0, c1 of (i, j), 3 inverse
+// transforms.  The reference inverse-transforms every product separately and sums in Int32
+// (:359-366); summing in the spectrum domain first gives the same words (both are the exact product
+// mod 2^32; rounding margin checked by the oracle test).
+struct MkBrArgs {
+    const int32_t *bara;  // [R][P*n+1]
+    const cplx *bk;       // [P][n][2*L*P + 2*L][8][64] spectra (engine order, scaled 1/M)
+    int32_t *ext;         // [R][P*N+1]
+    Tables T;
+    Gadget g;
+    int32_t n;
+    int32_t mu;
+};
+
+__device__ __forceinline__ void fft_fwd_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+    x1_store_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_b(lane, x, xch);
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    WAVE_LDS_FENCE();
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+    WAVE_LDS_FENCE();
+    dft8<false>(x);
+}
+
+__device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    dft8<true>(x);
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    dft8<true>(x);
+    WAVE_LDS_FENCE();
+    x1_store_b(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f[q]);
+    dft8<true>(x);
+}
+
+template <int L, int PARTY>
+__device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
+                                               cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask)
+{
+    constexpr int NP = 2;                         // parties
+    constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit)
+    const int beta = P.g.log2_base;
+#pragma unroll 1
+    for (int j = 0; j < P.n; j++) {
+        const int a = bara[PARTY * P.n + j] & (2 * kN - 1);
+        const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
+        cplx out[NP + 1][8];
+#pragma unroll
+        for (int d = 0; d <= NP; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
+            int32_t temp[16];
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                // key polys for this transform (mk_internals.jl:371-385)
+                const cplx *k_party, *k_body, *k_other = nullptr;
+                if (s < NP) {
+                    k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
+                    k_body = key + (size_t)(p * NP + s) * kM;                   // x[p, s]      -> b'
+                    if (s != PARTY) k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;   // y[p, party] -> a'_s
+                } else {
+                    k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
+                    k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
+                }
+                cplx kv[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_party[k2 * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kv[k2], out[PARTY][k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_body[k2 * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kv[k2], out[NP][k2]);
+                if (s < NP && s != PARTY) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_other[k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[s < NP ? s : 0][k2] = cfma(x[k2], kv[k2], out[s < NP ? s : 0][k2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d <= NP; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2(out[d], accr);
+            store_acc<2>(lane, accr, acc_lds + d * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
+{
+    constexpr int NP = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [kXchElems]
+    cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (NP * P.n + 1);
+    const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
+        const int barb = bara[NP * P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = 0;
+            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+    // party-major double loop (mk_internals.jl:475-476)
+    mk_party_steps<L, 0>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
+    mk_party_steps<L, 1>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
+
+    // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
+    int32_t *ext = P.ext + w * (NP * kN + 1);
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[c * kN] = v;
+            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
+}
+
+// ---- small batches: two waves per blind rotation ----------------------------------------------------
+// With fewer rotations than wave slots (single gates, sequential circuits, small batches) one wave per
+// rotation leaves the chip idle and a gate takes n x (4 forward + 2 inverse transforms) of latency.
+// Here wave c (c = 0: mask polynomial, c = 1: body) owns accumulator polynomial c: it rotates and
+// decomposes only its own polynomial, runs its L forward transforms, MACs both output components, hands
+// the partial sum for the other component over through LDS (double-buffered, ONE barrier per step), adds
+// what it receives, inverse-transforms its own component and updates its own polynomial.  Same arithmetic
+// per rotation as blind_rotate_kernel_v3, about half the latency.
+template <int L>
+__global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
+{
+    constexpr int K1 = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2 waves][kXchElems]
+    cplx *xfer = xch_all + 2 * kXchElems;                                        // [2 parity][2 waves][512]
+    cplx *tw2_lds = xfer + 2 * 2 * kM;                                           // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = tid >> 6;                                                     // wave = owned polynomial
+    int32_t *acc_lds = acc_all + wv * kN;
+    cplx *xch = xch_all + wv * kXchElems;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            const int32_t body = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+            acc_lds[lane + 64 * m] = wv ? body : 0;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN - 1);
+        // key polys of transform (p, c = wv): [i][p][c][co][8][64]
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
+        cplx own[8], oth[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); oth[q] = mk(0.0, 0.0); }
+        int32_t temp[16];
+        {
+            int32_t cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
+            rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
+        }
+#pragma unroll 1
+        for (int p = 0; p < L; p++) {
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            const cplx *kp = key + (size_t)p * K1 * K1 * kM;
+            cplx kown[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) kown[k2] = kp[(size_t)wv * kM + k2 * 64];           // co = wv (issued before the FFT)
+            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            cplx koth[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) koth[k2] = kp[(size_t)(1 - wv) * kM + k2 * 64];     // co = 1 - wv
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = cfma(x[k2], kown[k2], own[k2]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) oth[k2] = cfma(x[k2], koth[k2], oth[k2]);
+        }
+        // hand the other component's partial sum over (buffer by step parity: one barrier per step)
+        cplx *mine = xfer + ((i & 1) * 2 + wv) * kM, *theirs = xfer + ((i & 1) * 2 + (1 - wv)) * kM;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) mine[k2 * 64 + lane] = oth[k2];
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], theirs[k2 * 64 + lane]);
+        fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
+        int32_t accr[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
+        untwist_add2(own, accr);
+        store_acc<2>(lane, accr, acc_lds);
+        WAVE_LDS_FENCE();
+    }
+    __syncthreads();
+    int32_t *ext = P.ext + w * (kN + 1);
+    if (wv == 0) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int j = lane + 64 * m;
+            const int32_t v = acc_all[j];
+            if (j == 0) ext[0] = v;
+            else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+        }
+    } else if (lane == 0) {
+        ext[kN] = acc_all[kN];
+    }
+}
+
+// ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
+// Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
+// 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
+template <int L>
+__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
+{
+    constexpr int K1 = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
+    cplx *tw2_lds = xch + kXchElems;
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = 0;
+            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN - 1);
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + lane;
+        cplx out[K1][8];
+#pragma unroll
+        for (int d = 0; d < K1; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll 1
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[16];
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
+#pragma unroll
+                for (int co = 0; co < K1; co++) {
+                    cplx kv[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(co * 8 + k2) * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < K1; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2(out[d], accr);
+            store_acc<2>(lane, accr, acc_lds + d * kN);
+        }
+        WAVE_LDS_FENCE();
+    }
+    // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
+    int32_t *ext = P.ext + w * (2 * kN + 1);
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[c * kN] = v;
+            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
+}
+
+// ---- N = 2048: two waves per blind rotation ----------------------------------------------------------
+// M = 1024 folded points.  One radix-2 DIF stage is split across the two waves of a 128-thread block:
+//   a_j = z_j + z_{j+512}  -> wave 0 -> even frequencies,   b_j = (z_j - z_{j+512}) W_1024^j -> wave 1 -> odd,
+// then each wave runs the same 512-point transform as the N = 1024 kernels on its half, MACs its own
+// frequencies, inverse-transforms them, and the halves are recombined through LDS (2 barriers per inverse
+// transform).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
+//   wave 0 pass-A input  x_r = e^{-i pi r/32}  (u + kappa u'),   lane factor w^t             in tw1f
+//   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
+// Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
+constexpr int kN2 = 2048;
+
+__host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
+{
+    constexpr double T[17] = {1.0, 0.99518472667219692873, 0.98078528040323043058, 0.95694033573220882438,
+                              0.92387953251128673848, 0.88192126434835504956, 0.83146961230254523567,
+                              0.77301045336273699338, 0.70710678118654752440, 0.63439328416364548779,
+                              0.55557023301960228867, 0.47139673682599780857, 0.38268343236508983729,
+                              0.29028467725446233105, 0.19509032201612833135, 0.09801714032956077016, 0.0};
+    const int m = ((k % 64) + 64) % 64;
+    return m <= 16 ? T[m] : m <= 32 ? -T[32 - m] : m <= 48 ? -T[m - 32] : T[64 - m];
+}
+__host__ __device__ constexpr double sin_pi32(int k) { return cos_pi32(k - 16); }
+
+struct Br2048Args {
+    const int32_t *bara;   // [R][n+1]
+    const cplx *bk;        // [n][L][2][2][2 (wave)][8][64]
+    int32_t *ext;          // [R][N+1]
+    const cplx *tw1f2;     // [2 (wave)][8][64]
+    const cplx *tw2;       // [8][8]
+    Gadget g;
+    int32_t n, mu;
+};
+
+// pass-A input from the four coefficient classes of point jj = t + 64 r (values already converted to double)
+//   u = lo - i hi (coefficients jj, jj+1024), u' = lo2 - i hi2 (jj+512, jj+1536); sg = +sqrt(1/2) (wave 0) / -sqrt(1/2)
+template <int R>
+__device__ __forceinline__ cplx fwd_in_2048(double lo, double hi, double s2, double d2, double sg, bool wave1)
+{
+    // u +- kappa u' = (lo +- (lo2-hi2)/sqrt2) - i (hi +- (lo2+hi2)/sqrt2),  s2 = lo2-hi2, d2 = lo2+hi2
+    const double re = lo + sg * s2, im = hi + sg * d2;
+    if (R == 0) return mk(re, -im);
+    const double cr = wave1 ? cos_pi32(5 * R) : cos_pi32(R), sr = wave1 ? sin_pi32(5 * R) : sin_pi32(R);
+    return mk(re * cr - im * sr, -(re * sr + im * cr));          // (re - i im) e^{-i theta}
+}
+
+template <int MM>
+__device__ __forceinline__ void rotate_sub_2048(int lane, int a, const int32_t *acc_lds, int32_t offset, int32_t xormask, int32_t (&temp)[32])
+{
+    const int base = (lane - a) & (2 * kN2 - 1);
+#pragma unroll
+    for (int m = 0; m < 32; m++) {
+        const int idx = (base + 64 * m) & (2 * kN2 - 1);
+        const int32_t v = acc_lds[idx & (kN2 - 1)];
+        const int32_t cur = acc_lds[lane + 64 * m];
+        const uint32_t sgn = (idx & kN2) ? 0xFFFFFFFFu : 0u;
+        temp[m] = (int32_t)(((((uint32_t)v ^ sgn) - sgn) - (uint32_t)cur + (uint32_t)offset) ^ (uint32_t)xormask);
+    }
+}
+
+// forward 512-point transform of this wave's half (after the radix-2 split), x in / spectrum out
+__device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
+{
+    fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+}
+
+template <int L>
+__global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P)
+{
+    constexpr int K1 = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                         // [K1][2048]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN2 * 4);                // [2 waves][kXchElems]
+    cplx *tw2_lds = xch_all + 2 * kXchElems;                                      // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave1 = (tid >> 6) != 0;                                           // wave-uniform
+    cplx *xch = xch_all + (wave1 ? kXchElems : 0);
+    cplx *xch_other = xch_all + (wave1 ? 0 : kXchElems);
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+    const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1 ? 512 : 0) + q * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = P.tw2[tid];
+    {
+        const int barb = bara[P.n] & (2 * kN2 - 1);
+        for (int j = tid; j < kN2; j += 128) {
+            const int idx = (j + barb) & (2 * kN2 - 1);
+            acc_lds[j] = 0;
+            acc_lds[kN2 + j] = (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * kN2 - 1);
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;
+        cplx out[K1][8];
+#pragma unroll
+        for (int d = 0; d < K1; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll 1
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[32];
+            {
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub_2048<0>(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
+            }
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+#define FWD_IN(R)                                                                                          \
+    {                                                                                                      \
+        const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);            \
+        const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);      \
+        x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);    \
+    }
+                FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
+#undef FWD_IN
+                fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
+#pragma unroll
+                for (int co = 0; co < K1; co++) {
+                    cplx kv[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)co * 2 * kM + k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
+                }
+            }
+        }
+        __syncthreads();   // every rotated read of this step is done before anybody updates acc_lds
+#pragma unroll
+        for (int d = 0; d < K1; d++) {
+            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);          // alpha (wave 0) / beta (wave 1)
+#pragma unroll
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[d][r];
+            __syncthreads();
+            cplx oth[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+            __syncthreads();
+            // wave 0: (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024
+            // wave 1: (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
+#define COMBINE(R)                                                                                         \
+    {                                                                                                      \
+        const cplx al = wave1 ? oth[R] : out[d][R], be = wave1 ? out[d][R] : oth[R];                       \
+        const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);           /* e_r = e^{-i pi r/8} */      \
+        const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er; /* conj(beta) e_r: re, im */  \
+        const double vr = wave1 ? al.x - br : al.x + br;                     /* conj(alpha) = (al.x, -al.y) */ \
+        const double vi = wave1 ? -al.y - bi : -al.y + bi;                                                 \
+        const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R); \
+        const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;                                       \
+        const int jlo = lane + 64 * R + (wave1 ? 512 : 0);                                                 \
+        int32_t *ap = acc_lds + d * kN2;                                                                   \
+        ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));                           \
+        ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));             \
+    }
+            COMBINE(0) COMBINE(1) COMBINE(2) COMBINE(3) COMBINE(4) COMBINE(5) COMBINE(6) COMBINE(7)
+#undef COMBINE
+        }
+        __syncthreads();
+    }
+
+    int32_t *ext = P.ext + w * (kN2 + 1);
+    for (int j = tid; j < kN2; j += 128) {
+        const int32_t v = acc_lds[j];
+        if (j == 0) ext[0] = v;
+        else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (tid == 0) ext[kN2] = acc_lds[kN2];
+}
+
+// key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024
+__global__ __launch_bounds__(128) void bk_prepare_kernel_n2048(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out,
+                                                             const cplx *__restrict__ tw1f2, const cplx *__restrict__ tw2)
+{
+    __shared__ __attribute__((aligned(16))) cplx xch_all[2 * kXchElems + 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool wave1 = (tid >> 6) != 0;
+    cplx *xch = xch_all + (wave1 ? kXchElems : 0);
+    cplx *tw2_lds = xch_all + 2 * kXchElems;
+    const size_t q = blockIdx.x;
+    const int32_t *poly = bk_i32 + q * kN2;
+    const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
+    cplx tw1f[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; qq++) tw1f[qq] = tw1f2[(wave1 ? 512 : 0) + qq * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = tw2[tid];
+    __syncthreads();
+    cplx x[8];
+#define FWD_IN(R)                                                                                          \
+    {                                                                                                      \
+        const double lo = (double)poly[lane + 64 * R], l2 = (double)poly[lane + 64 * R + 512];             \
+        const double hi = (double)poly[lane + 64 * R + 1024], h2 = (double)poly[lane + 64 * R + 1536];     \
+        x[R] = fwd_in_2048<R>(lo, hi, l2 - h2, l2 + h2, sg, wave1);                                        \
+    }
+    FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
+#undef FWD_IN
+    fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+    const double s = 1.0 / 1024.0;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) out[q * 2 * kM + (wave1 ? kM : 0) + k2 * 64 + lane] = mk(x[k2].x * s, x[k2].y * s);
+}
+
+// the reference's spectra for N = 2048 (natural order, 1024 values) -> engine order
+__global__ __launch_bounds__(128) void bk_permute_c128_kernel_n2048(const cplx *__restrict__ in, cplx *__restrict__ out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t q = blockIdx.x;
+    const double s = 1.0 / 1024.0;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const cplx v = in[q * 2 * kM + 2 * freq_of(lane, k2) + wv];
+        out[q * 2 * kM + wv * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
+    }
+}
+
+// Bootstrapping-key preparation: Int32 polynomial -> spectrum in the engine's order, scaled 1/M.
+// (the analogue of forward_transform.(bk), bootstrap.jl:12)
+__global__ __launch_bounds__(64) void bk_prepare_kernel(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out, Tables T)
+{
+    __shared__ __attribute__((aligned(16))) cplx xch[kXchElems];
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    cplx x[8];
+    load_poly(lane, bk_i32 + q * kN, T, x);
+    fwd_pass_a(lane, x, T);
+    x1_store_a(lane, x, xch);
+    __syncthreads();
+    x1_load_b(lane, x, xch);
+    __syncthreads();
+    fwd_pass_b(lane, x, T);
+    x2_store(lane, x, xch);
+    __syncthreads();
+    x2_load(lane, x, xch);
+    __syncthreads();
+    fwd_pass_c(x);
+    const double s = 1.0 / kM;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) out[q * kM + k2 * 64 + lane] = mk(x[k2].x * s, x[k2].y * s);
+}
+
+// The reference's stored spectra (natural frequency order, polynomials.jl:106-112) -> engine order.
+__global__ __launch_bounds__(64) void bk_permute_c128_kernel(const cplx *__restrict__ in, cplx *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const double s = 1.0 / kM;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+        const cplx v = in[q * kM + freq_of(lane, k2)];
+        out[q * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
+    }
+}
+
