@@ -214,3 +214,55 @@ def test_gate_parity_synthetic_n2048(tfhe, orc):
     assert np.array_equal(e2.bootstrap(2**29, x, with_keyswitch=False), ext)
     e2.close()
     K.ck.close()
+
+
+@pytest.mark.parametrize("B", [2, 31, 33, 65, 255, 257, 513])
+def test_ragged_batch_sizes(tfhe, orc, keys80, eng80, B):
+    """Batch sizes straddling every tile edge (MFMA keyswitch tiles of 32/64/256 samples, the 512-rotation switch
+    between the two-wave and one-wave blind-rotate kernels): all bit-equal to the oracle."""
+    K = keys80
+    rng = np.random.default_rng(B)
+    names = ["NAND", "XOR", "MUX", "NOT", "ANDYN"]
+    ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+    got = eng80.gates(ops, *ins)
+    assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=16))
+
+
+def test_maximum_lwe_size(tfhe, orc):
+    """lwe_size = 1023, the largest the engine accepts (n + 1 = 1024 output words); 1024 is rejected loudly."""
+    from conftest import KeySet
+    p = tfhe.SchemeParameters(1023, 1 / 2**17, 1024, 1, 2, 10, 9e-9, 8, 2, 1 / 2**17, 1)
+    K = KeySet(tfhe, orc, p, seed=1023)
+    eng = K.ck.engine(0)
+    x = tfhe.encrypt(K.rng, K.sk, [True, False, True, False]).data
+    y = tfhe.encrypt(K.rng, K.sk, [True, True, False, False]).data
+    ops = np.zeros(4, np.uint8)
+    got = eng.gates(ops, x, y)
+    assert np.array_equal(got, K.oracle.gates(ops, x, y, nthreads=4))
+    assert list(tfhe.decrypt(K.sk, got)) == [False, True, True, True]
+    K.ck.close()
+    with pytest.raises(tfhe.EngineError):
+        tfhe.Engine(tfhe.SchemeParameters(1024, 0.0, 1024, 1, 2, 10, 0.0, 8, 2, 0.0, 1), 0)
+
+
+def test_config3_full_size_mixed_stream(tfhe, keys80, eng80):
+    """BASELINE config 3 at full size on one GPU: 65 536 i.i.d. {NAND, AND, OR, XOR, MUX} gates (seed 789).
+    Size-independent properties: every output decrypts to the gate's truth value; rotation count = gates + MUXes;
+    a contiguous shard computed alone equals the same rows of the full batch (what multi-GPU sharding relies on)."""
+    from tfhe_jl_amd.sharding import shard_bounds
+    K = keys80
+    rng = np.random.default_rng(789)
+    B = 65536
+    names = ["NAND", "AND", "OR", "XOR", "MUX"]
+    sel = rng.integers(0, 5, B)
+    ops = np.array([tfhe.OPCODES[n] for n in names], np.uint8)[sel]
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
+    got = eng80.gates(ops, *ins)
+    x, y, z = bits
+    want = np.select([sel == 0, sel == 1, sel == 2, sel == 3, sel == 4], [~(x & y), x & y, x | y, x ^ y, np.where(x, y, z)])
+    assert np.array_equal(tfhe.decrypt(K.sk, got), want)
+    assert eng80.last_rotation_count() == B + int((sel == 4).sum())
+    s, e = shard_bounds(ops, 8)[3]
+    assert np.array_equal(eng80.gates(ops[s:e], *[a[s:e] for a in ins]), got[s:e])
