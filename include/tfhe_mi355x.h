@@ -176,7 +176,12 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
 /* Number of blind rotations the most recent batch call executed (MUX counts 2). */
 int64_t tfhe_last_rotation_count(const tfhe_ctx *ctx);
 
-/* Selects a kernel variant by name for tuning / A-B benchmarking ("" or NULL = default). */
+/* Exactness evidence for the Float64 transform: after tfhe_set_option(ctx, "measure_margin", 1), batch calls
+ * also record, per blind rotation, the largest distance of any pre-rounding value from an integer
+ * (polynomials.jl:115-116 rounds; a flipped rounding needs 0.5).  Returns the maximum over the last call. */
+int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
+
+/* Selects a kernel variant / diagnostic by name ("br_variant", "ks_variant", "br_small", "measure_margin"). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

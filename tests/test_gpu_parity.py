@@ -266,3 +266,20 @@ def test_config3_full_size_mixed_stream(tfhe, keys80, eng80):
     assert eng80.last_rotation_count() == B + int((sel == 4).sum())
     s, e = shard_bounds(ops, 8)[3]
     assert np.array_equal(eng80.gates(ops[s:e], *[a[s:e] for a in ins]), got[s:e])
+
+
+def test_gpu_rounding_margin(tfhe, keys80, eng80, keys128, eng128):
+    """The engine's own Float64 transform must stay far from a flipped rounding (assert the
+    margin of the GPU FFT itself, not only the oracle's): max |pre-round value - nearest integer| < 0.25."""
+    for K, eng in ((keys80, eng80), (keys128, eng128)):
+        B = 256
+        x = tfhe.encrypt(K.rng, K.sk, K.rng.integers(0, 2, B).astype(bool)).data
+        y = tfhe.encrypt(K.rng, K.sk, K.rng.integers(0, 2, B).astype(bool)).data
+        ops = np.zeros(B, np.uint8)
+        ref = eng.gates(ops, x, y)
+        eng.set_option("measure_margin", 1)
+        got = eng.gates(ops, x, y)
+        margin = eng.last_rounding_margin()
+        eng.set_option("measure_margin", 0)
+        assert np.array_equal(got, ref)
+        assert 0.0 < margin < 0.25, margin

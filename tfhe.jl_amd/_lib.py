@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "tfhe_load_keyswitch_key", "tfhe_gates_batch", "tfhe_gates_batch_dev", "tfhe_bootstrap_batch",
     "tfhe_keyswitch_batch", "tfhe_mk_load_bootstrap_key_i32", "tfhe_mk_load_keyswitch_key",
     "tfhe_mk_gate_nand_batch", "tfhe_last_timing_ms", "tfhe_last_rotation_count", "tfhe_set_option",
-    "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
+    "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
 ]
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
@@ -71,6 +71,7 @@ def load():
     lib.tfhe_last_rotation_count.argtypes = [vp]
     lib.tfhe_last_rotation_count.restype = i64
     lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.tfhe_last_rounding_margin.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tfhe_wires_alloc.argtypes = [vp, i64]
     lib.tfhe_wires_upload.argtypes = [vp, i64, i64, vp]
     lib.tfhe_wires_download.argtypes = [vp, i64, i64, vp]
@@ -226,6 +227,11 @@ class Engine:
 
     def last_rotation_count(self):
         return int(self._lib.tfhe_last_rotation_count(self._h))
+
+    def last_rounding_margin(self):
+        m = C.c_double(0)
+        self._check(self._lib.tfhe_last_rounding_margin(self._h, C.byref(m)))
+        return float(m.value)
 
     def set_option(self, name, value):
         self._check(self._lib.tfhe_set_option(self._h, name.encode(), int(value)))

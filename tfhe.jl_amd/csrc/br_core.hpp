@@ -378,14 +378,29 @@ TFHE_HD void inv2_pass_a(cplx (&x)[8], const LaneTw &w)
     for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], w.tw1f[q]);
     dft8<true>(x);
 }
-// conj(y) * e^{-i pi r/16}: real -> coefficient t+64r, imag -> t+64r+512; round, add into acc
-TFHE_HD void untwist_add2(const cplx (&y)[8], int32_t (&acc)[16])
+// distance of v from the nearest integer (rounding-margin diagnostics; |v| < 2^51)
+TFHE_HD double frac_dist(double v)
+{
+    const double r = (v + 6755399441055744.0) - 6755399441055744.0;   // round to nearest integer
+    const double d = v - r;
+    return d < 0 ? -d : d;
+}
+
+// conj(y) * e^{-i pi r/16}: real -> coefficient t+64r, imag -> t+64r+512; round, add into acc.
+// MARGIN: also track the largest distance of a pre-round value from an integer (must stay << 0.5).
+template <bool MARGIN = false>
+TFHE_HD void untwist_add2(const cplx (&y)[8], int32_t (&acc)[16], double *worst = nullptr)
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         double re, im;
         if (r == 0) { re = y[r].x; im = -y[r].y; }
         else { re = y[r].x * twc(r) - y[r].y * tws(r); im = -(y[r].x * tws(r) + y[r].y * twc(r)); }
+        if (MARGIN) {
+            const double a = frac_dist(re), b = frac_dist(im);
+            if (a > *worst) *worst = a;
+            if (b > *worst) *worst = b;
+        }
         acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
         acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(im));
     }

@@ -9,6 +9,7 @@
 using namespace tfhe;
 
 struct BrArgs {
+    double *margin;       // [R] worst rounding margin per rotation (only written by the MARGIN instantiation)
     const int32_t *bara;  // [R][n+1], barb last
     const cplx *bk;       // [n][L][K1][K1][8][64] spectra, permuted order, scaled by 1/M
     int32_t *ext;         // [R][(K1-1)*N + 1]
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
 //   * key spectra of the next transform prefetched into registers while the current FFT runs;
 //   * no s_barrier: wave-private LDS needs only compiler-level ordering;
 //   * no branch on bara[i] == 0 (the step then adds exactly zero).
-template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */>
+template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */,
+          bool MARGIN = false /* diagnostics: record the worst distance of a pre-round value from an integer */>
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 {
     constexpr int K1 = 2;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     }
     WAVE_LDS_FENCE();
 
+    double worst = 0.0;
     cplx kbuf[16];
     // chunk f of step: key spectra for transform f = (c, p): 16 values per lane (co-major, k2 minor)
     auto key_ptr = [&](int step, int f) {
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
             int32_t accr[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + lane + 64 * m];
-            untwist_add2(out[co], accr);
+            untwist_add2<MARGIN>(out[co], accr, &worst);
             store_acc<K1>(lane, accr, acc_lds + co * kN);
         }
         WAVE_LDS_FENCE();
@@ -295,6 +298,14 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
     }
     if (lane == 0) ext[kN] = acc_lds[kN];
+    if (MARGIN) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(worst, off);
+            worst = o > worst ? o : worst;
+        }
+        if (lane == 0) P.margin[w] = worst;
+    }
 }
 
 // ---- multi-key blind rotation (2 parties) ----------------------------------------------------------

@@ -81,7 +81,9 @@ struct tfhe_ctx {
     int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
-    DevBuf bara, ext, map, io[4];
+    DevBuf bara, ext, map, io[4], margin;
+    size_t margin_rows = 0;
+    bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations also record their rounding margin
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
 
@@ -203,7 +205,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
-    c->bara.release(); c->ext.release(); c->map.release();
+    c->bara.release(); c->ext.release(); c->map.release(); c->margin.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -308,7 +310,9 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 // ---- launch helpers ------------------------------------------------------------------------------
 static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
 {
+    c->margin_rows = 0;
     BrArgs a;
+    a.margin = nullptr;
     a.bara = (const int32_t *)c->bara.p;
     a.bk = c->d_bk;
     a.ext = (int32_t *)c->ext.p;
@@ -342,7 +346,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
     }
-    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2) {
+    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2 && !c->measure_margin) {
         const size_t ldsw = 2 * kN * 4 + (2 * kXchElems + 4 * kM + 64) * sizeof(cplx);
         switch (c->P.bs_l) {
         case 1: hipLaunchKernelGGL((blind_rotate_kernel_w2<1>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
@@ -352,6 +356,21 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
         }
         HIP_TRY(c, hipGetLastError());
+        return TFHE_OK;
+    }
+    if (c->measure_margin && c->P.k == 1 && c->P.N == kN) {   // diagnostics: same kernel, MARGIN instantiation
+        const size_t ldsm = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+        HIP_TRY(c, c->margin.reserve(R * sizeof(double)));
+        a.margin = (double *)c->margin.p;
+        switch (c->P.bs_l) {
+        case 1: hipLaunchKernelGGL((blind_rotate_kernel_v3<1, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
+        case 2: hipLaunchKernelGGL((blind_rotate_kernel_v3<2, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
+        case 3: hipLaunchKernelGGL((blind_rotate_kernel_v3<3, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
+        case 4: hipLaunchKernelGGL((blind_rotate_kernel_v3<4, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
+        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
+        }
+        HIP_TRY(c, hipGetLastError());
+        c->margin_rows = R;
         return TFHE_OK;
     }
     if (c->br_variant >= 2) {
@@ -899,6 +918,20 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
 
 int64_t tfhe_last_rotation_count(const tfhe_ctx *c) { return c ? c->last_rotations : -1; }
 
+int32_t tfhe_last_rounding_margin(tfhe_ctx *c, double *worst)
+{
+    if (!c || !worst) return TFHE_ERR_INVALID_ARG;
+    if (!c->margin_rows) return c->set_err(TFHE_ERR_STATE, "last_rounding_margin: enable tfhe_set_option(\"measure_margin\", 1) before the batch call (N = 1024, k = 1)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<double> h(c->margin_rows);
+    HIP_TRY(c, hipMemcpy(h.data(), c->margin.p, c->margin_rows * sizeof(double), hipMemcpyDeviceToHost));
+    double m = 0;
+    for (double v : h) m = v > m ? v : m;
+    *worst = m;
+    return TFHE_OK;
+}
+
 int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
@@ -909,6 +942,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
+    if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "ks_variant")) {
         if (value != 1 && value != 3 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 3 or 4");
         c->ks_variant = (int)value;
