@@ -158,7 +158,7 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *ctx, const int32_t *in, int32_t *out, int
 
 /* ---- multi-key (mk_gates.jl:7-12, mk_internals.jl:348-411,464-515) --------------------------- */
 
-/* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file). */
+/* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file); 2 <= P <= 8, P <= the context's `parties`. */
 int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk, int32_t parties);
 /* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]. */
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks, int32_t parties);

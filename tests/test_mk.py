@@ -76,3 +76,53 @@ def test_mk_gpu_parity(orc, tfhe, mk_full):
     one = tfhe.mk_gate_nand(K.ck, x[0], y[0])
     assert one.shape == (1001,) and np.array_equal(one, want[0])
     K.ck.close()
+
+
+def _mk_setup(tfhe, orc, base, parties, n, seed):
+    p = tfhe.SchemeParameters(n, base.lwe_noise_stddev, 1024, 1, base.bs_decomp_length, base.bs_log2_base,
+                              base.bs_noise_stddev, base.ks_decomp_length, base.ks_log2_base, base.ks_noise_stddev,
+                              base.max_parties)
+    rng = np.random.default_rng(seed)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    o = orc.Oracle(n, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=parties)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    return p, rng, sks, ck, o
+
+
+@pytest.mark.parametrize("which,parties,n", [("4party", 4, 12), ("4party", 3, 12), ("8party", 8, 6)])
+def test_mk_oracle_backends_agree_many_parties(orc, tfhe, which, parties, n):
+    """mktfhe_parameters_4party / _8party (mk_api.jl:16-34; reduced lwe_size): FFT and exact back-ends agree."""
+    base = getattr(tfhe, "mktfhe_parameters_" + which)
+    p, rng, sks, ck, o = _mk_setup(tfhe, orc, base, parties, n, seed=40 + parties)
+    assert ck.bootstrap_key.shape == (parties, n, 2 * p.bs_decomp_length * parties + 2 * p.bs_decomp_length, 1024)
+    x = tfhe.mk_encrypt(rng, sks, [True, False])
+    y = tfhe.mk_encrypt(rng, sks, [True, True])
+    a = o.mk_gate_nand(x, y, mode=orc.MODE_FFT)
+    assert o.last_margin < 0.25
+    assert np.array_equal(a[:1], o.mk_gate_nand(x[:1], y[:1], mode=orc.MODE_EXACT))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,parties,n", [("2party", 2, 24), ("4party", 4, 12), ("4party", 3, 12), ("8party", 8, 6)])
+def test_mk_gpu_parity_many_parties(orc, tfhe, which, parties, n):
+    """The any-P multi-key kernel against the oracle, word for word; for 2 parties also against
+    the specialised 2-party kernel."""
+    base = getattr(tfhe, "mktfhe_parameters_" + which)
+    p, rng, sks, ck, o = _mk_setup(tfhe, orc, base, parties, n, seed=40 + parties)
+    B = 5
+    x = rng.integers(-2**31, 2**31, size=(B, parties * n + 1), dtype=np.int64).astype(np.int32)
+    y = rng.integers(-2**31, 2**31, size=(B, parties * n + 1), dtype=np.int64).astype(np.int32)
+    x[:2] = tfhe.mk_encrypt(rng, sks, [True, False])
+    y[:2] = tfhe.mk_encrypt(rng, sks, [True, True])
+    eng = ck.engine(0)
+    if parties == 2:
+        special = eng.mk_gate_nand(x, y)
+        eng.set_option("mk_general", 1)
+    got = eng.mk_gate_nand(x, y)
+    assert np.array_equal(got, o.mk_gate_nand(x, y, nthreads=5))
+    if parties == 2:
+        assert np.array_equal(got, special)
+    ck.close()

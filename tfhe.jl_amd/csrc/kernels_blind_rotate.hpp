@@ -481,6 +481,127 @@ __global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
     if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
 }
 
+// ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
+// Same algorithm as mk_blind_rotate_kernel with run-time P and L.  Only three spectrum accumulators are ever
+// live whatever P is: in step (party i, bit j) the new mask a'_s of a non-party s receives products of its OWN
+// digits only (mk_internals.jl:377-378), so it is inverse-transformed and written back right after source s's
+// L transforms (nobody else reads acc[s] in this step); a'_party and b' accumulate over all sources
+// (:371-376, :382-385).
+struct MkGenArgs {
+    const int32_t *bara;  // [R][P*n+1]
+    const cplx *bk;       // [P][n][2*L*P + 2*L][8][64]
+    int32_t *ext;         // [R][P*N+1]
+    Tables T;
+    Gadget g;
+    int32_t n, mu, parties, L;
+};
+
+__global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArgs P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NP = P.parties, L = P.L;
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + (size_t)(NP + 1) * kN * 4);
+    cplx *tw2_lds = xch + kXchElems;
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * ((size_t)NP * P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+    const int per = 2 * L * NP + 2 * L;
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    tw2_lds[lane] = P.T.tw2[lane];
+    {
+        const int barb = bara[(size_t)NP * P.n] & (2 * kN - 1);
+        for (int s = 0; s < NP; s++)
+#pragma unroll
+            for (int m = 0; m < 16; m++) acc_lds[s * kN + lane + 64 * m] = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[NP * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    WAVE_LDS_FENCE();
+
+    auto finish = [&](cplx (&o)[8], int d) {      // inverse transform, round, add into accumulator polynomial d
+        fft_inv_wave(lane, o, tw1f, tw2_lds, xch);
+        int32_t accr[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+        untwist_add2(o, accr);
+        store_acc<2>(lane, accr, acc_lds + d * kN);
+    };
+
+#pragma unroll 1
+    for (int party = 0; party < NP; party++) {                               // mk_internals.jl:475
+#pragma unroll 1
+        for (int j = 0; j < P.n; j++) {                                      // :476
+            const int a = bara[(size_t)party * P.n + j] & (2 * kN - 1);
+            const cplx *key = P.bk + ((size_t)party * P.n + j) * per * kM + lane;
+            cplx o_party[8], o_body[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { o_party[q] = mk(0.0, 0.0); o_body[q] = mk(0.0, 0.0); }
+#pragma unroll 1
+            for (int s = 0; s <= NP; s++) {
+                const bool is_body = (s == NP), has_self = (!is_body && s != party);
+                cplx o_self[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) o_self[q] = mk(0.0, 0.0);
+                int32_t temp[16];
+                {
+                    int32_t cur[16];
+#pragma unroll
+                    for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
+                    rotate_sub2(lane, a, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
+                }
+#pragma unroll 1
+                for (int p = 0; p < L; p++) {
+                    cplx x[8];
+                    load_digits2(temp, p + 1, beta, x);
+                    fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                    const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]
+                    const cplx *k_body = key + (size_t)(is_body ? 2 * L * NP + p : p * NP + s) * kM;                 // c0[p] | x[p, s]
+                    cplx kv[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_party[k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cfma(x[k2], kv[k2], o_party[k2]);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_body[k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cfma(x[k2], kv[k2], o_body[k2]);
+                    if (has_self) {
+                        const cplx *k_self = key + (size_t)(L * NP + p * NP + party) * kM;                           // y[p, party]
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_self[k2 * 64];
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) o_self[k2] = cfma(x[k2], kv[k2], o_self[k2]);
+                    }
+                }
+                if (has_self) finish(o_self, s);     // a'_s complete: only source s feeds it, only source s read acc[s]
+            }
+            finish(o_party, party);
+            finish(o_body, NP);
+            WAVE_LDS_FENCE();
+        }
+    }
+
+    int32_t *ext = P.ext + w * ((size_t)NP * kN + 1);
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[(size_t)c * kN] = v;
+            else ext[(size_t)c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[(size_t)NP * kN] = acc_lds[NP * kN];
+}
+
 // ---- small batches: two waves per blind rotation ----------------------------------------------------
 // With fewer rotations than wave slots (single gates, sequential circuits, small batches) one wave per
 // rotation leaves the chip idle and a gate takes n x (4 forward + 2 inverse transforms) of latency.

@@ -83,6 +83,7 @@ struct tfhe_ctx {
     // workspaces
     DevBuf bara, ext, map, io[4], margin;
     size_t margin_rows = 0;
+    bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations also record their rounding margin
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
@@ -155,7 +156,9 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: N = 2048 is supported with tlwe_mask_size 1, single key");
     if (p.k != 1 && p.k != 2) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 or 2");
     if (p.k != 1 && p.parties != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key needs tlwe_mask_size 1 (as the reference, mk_internals.jl:89-91)");
-    if (p.bs_l > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 unsupported");
+    if (p.bs_l > (p.parties > 1 ? 8 : 4))
+        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 (single key) / > 8 (multi-key) unsupported");
+    if (p.parties > 8) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: more than 8 parties unsupported");
     if (p.n + 1 > 1024) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: lwe_size + 1 > 1024 unsupported");
 
     int ndev = 0;
@@ -754,7 +757,8 @@ int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t p
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!bk) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: NULL key pointer");
-    if (parties != 2 || c->P.parties < 2) return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_bootstrap_key: this build supports exactly 2 parties on a context created with parties >= 2");
+    if (parties < 2 || parties > 8 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t per = (size_t)2 * c->P.bs_l * parties + 2 * c->P.bs_l;
     const size_t npolys = (size_t)parties * c->P.n * per;
@@ -779,7 +783,8 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: NULL key pointer");
-    if (parties != 2 || c->P.parties < 2) return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: this build supports exactly 2 parties on a context created with parties >= 2");
+    if (parties < 2 || parties > 8 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: parties must be 2..8 and not exceed the context's max_parties");
     if (c->P.ks_log2_base != 2 || c->P.ks_t % 4 != 0 || c->P.N % KS3_SLICES != 0 || c->P.N / KS3_SLICES > 128)
         return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: keyswitch base must be 4 and t a multiple of 4");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -851,12 +856,20 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     MkBrArgs a;
     a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
     a.n = n; a.mu = (int32_t)(1u << 29);
-    const size_t lds = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-    switch (c->P.bs_l) {
-    case 2: hipLaunchKernelGGL((mk_blind_rotate_kernel<2>), dim3((unsigned)B), dim3(64), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((mk_blind_rotate_kernel<3>), dim3((unsigned)B), dim3(64), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((mk_blind_rotate_kernel<4>), dim3((unsigned)B), dim3(64), lds, s, a); break;
-    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "mk blind rotate: bs_l = %d unsupported", c->P.bs_l);
+    const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+    const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
+    if (special) {
+        switch (c->P.bs_l) {
+        case 2: hipLaunchKernelGGL((mk_blind_rotate_kernel<2>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+        case 3: hipLaunchKernelGGL((mk_blind_rotate_kernel<3>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+        default: hipLaunchKernelGGL((mk_blind_rotate_kernel<4>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+        }
+    } else {
+        MkGenArgs ga;
+        ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
+        if (lds > 64 * 1024)
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mk_blind_rotate_kernel_general, dim3((unsigned)B), dim3(64), lds, s, ga);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -943,6 +956,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "ks_variant")) {
         if (value != 1 && value != 3 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 3 or 4");
         c->ks_variant = (int)value;
