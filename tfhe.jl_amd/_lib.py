@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtfhe_mi355x.so")
+LIB_PATH = os.environ.get("TFHE_MI355X_LIB", os.path.join(_PKG, "lib", "libtfhe_mi355x.so"))   # override: A/B builds
 
 # symbols include/tfhe_mi355x.h declares (tests check that the .so exports every one of them)
 ABI_SYMBOLS = [

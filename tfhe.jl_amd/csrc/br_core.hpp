@@ -166,7 +166,10 @@ TFHE_HD void x1_store_a(int lane, const cplx (&x)[8], cplx *xch)
 TFHE_HD void x1_load_a(int lane, cplx (&x)[8], const cplx *xch)
 {
 #pragma unroll
-    for (int q = 0; q < 8; q++) x[q] = xch[x1_a(lane, q)];
+    for (int o = 0; o < 8; o++) {
+        const int q = o;
+        x[q] = xch[x1_a(lane, q)];
+    }
 }
 TFHE_HD void x1_store_b(int lane, const cplx (&x)[8], cplx *xch)
 {
@@ -176,7 +179,10 @@ TFHE_HD void x1_store_b(int lane, const cplx (&x)[8], cplx *xch)
 TFHE_HD void x1_load_b(int lane, cplx (&x)[8], const cplx *xch)
 {
 #pragma unroll
-    for (int s = 0; s < 8; s++) x[s] = xch[x1_b(lane, s)];
+    for (int o = 0; o < 8; o++) {
+        const int s = o;
+        x[s] = xch[x1_b(lane, s)];
+    }
 }
 TFHE_HD void x2_store(int lane, const cplx (&x)[8], cplx *xch)
 {
@@ -186,7 +192,10 @@ TFHE_HD void x2_store(int lane, const cplx (&x)[8], cplx *xch)
 TFHE_HD void x2_load(int lane, cplx (&x)[8], const cplx *xch)
 {
 #pragma unroll
-    for (int v = 0; v < 8; v++) x[v] = xch[x2_r(lane, v)];
+    for (int o = 0; o < 8; o++) {
+        const int v = o;
+        x[v] = xch[x2_r(lane, v)];
+    }
 }
 
 // ---- torus / integer pieces ---------------------------------------------------------------------
