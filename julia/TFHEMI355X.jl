@@ -137,4 +137,14 @@ gate_not(gck::GpuCloudKey, x::LweSample) = TFHE.LweSample(x.params, -x.a, -x.b, 
 gate_constant(gck::GpuCloudKey, value::Bool) =
     TFHE.lwe_noiseless_trivial(TFHE.encode_message(value ? 1 : -1, 8), LweParams(gck.params.lwe_size))
 
+# ---- multi-key (src/mk_gates.jl:7-12) ----------------------------------------------------------------------
+# GpuMKCloudKey(ck::TFHE.MKCloudKey): flatten ck.bootstrap_key.key[j, i] (x[l, P], y[l, P], c0[l], c1[l] spectra;
+# src/mk_internals.jl:274-288,442-461) by applying TFHE.inverse_transform to every spectrum (exact: integers) into
+# Int32 [P][n][2lP + 2l][N] (x[p, q] at p*P + q, then y, c0, c1), call tfhe_mk_load_bootstrap_key_i32, flatten the
+# P keyswitch keys as in GpuCloudKey and call tfhe_mk_load_keyswitch_key; an MKLweSample is the Int32 column
+# [a[:, 1]; a[:, 2]; ...; b] (src/mk_internals.jl:6-18).  mk_gate_nand(gck, x, y) is then one ccall:
+#
+#   ccall((:tfhe_mk_gate_nand_batch, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64),
+#         gck.ctx, fx, fy, out, B)
+
 end # module
