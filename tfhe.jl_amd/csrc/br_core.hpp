@@ -340,17 +340,26 @@ TFHE_HD void rotate_sub2(int lane, int a_mod_2N, const int32_t *acc_lds, const i
     const int base = (lane - a_mod_2N) & (2 * kN - 1);
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-        const int idx = (base + 64 * m) & (2 * kN - 1);
+        const int idx = base + 64 * m;                         // bit 10 (mod 2N) = sign, low 10 bits = position
         const int32_t v = acc_lds[idx & (kN - 1)];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TFHE_NO_BFE)
+        const uint32_t sgn = (uint32_t)__builtin_amdgcn_sbfe(idx, 10u, 1u);     // 0 or 0xFFFFFFFF
+#else
         const uint32_t sgn = (idx & kN) ? 0xFFFFFFFFu : 0u;
-        const uint32_t r = ((uint32_t)v ^ sgn) - sgn;
-        temp[m] = (int32_t)((r - (uint32_t)cur[m] + (uint32_t)offset) ^ (uint32_t)xormask);
+#endif
+        // (v ^ sgn) - sgn - cur + offset, grouped so that one add folds the sign correction into the constant part
+        const uint32_t w = (uint32_t)offset - (uint32_t)cur[m] - sgn;
+        temp[m] = (int32_t)((((uint32_t)v ^ sgn) + w) ^ (uint32_t)xormask);
     }
 }
-// digit p (1-based) of a prepared coefficient: signed bit-field extract
+// digit p (1-based) of a prepared coefficient: signed bit-field extract of bits [32 - p beta, 32 - (p-1) beta)
 TFHE_HD int32_t digit2(int32_t t, int p, int log2_base)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TFHE_NO_BFE)
+    return __builtin_amdgcn_sbfe(t, (unsigned)(32 - p * log2_base), (unsigned)log2_base);   // one v_bfe_i32
+#else
     return (int32_t)((uint32_t)t << ((p - 1) * log2_base)) >> (32 - log2_base);
+#endif
 }
 // x[r] = (d[t+64r] - i d[t+64r+512]) * e^{-i pi r/16}
 TFHE_HD void load_digits2(const int32_t (&temp)[16], int p, int log2_base, cplx (&x)[8])
