@@ -217,6 +217,8 @@ struct Ks4Args {
     int32_t n, kN, G, wtiles;
     int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
     int32_t add_b;          // 1: out[out_b] = ext b (+ MUX constant) - sum; 0 (MK party > 0): accumulate into out_b
+    const i32x4 *abar_t;    // [kN/4][Gpad] rounded mask words, 4 consecutive words of one sample per element (ks4_digits_kernel)
+    int32_t Gpad;           // samples rounded up to a multiple of 64
     int32_t kslices;        // > 1 (small batches): blockIdx.z takes kN/kslices mask words, results combined with
                             // integer atomics into an output pre-initialised to (0, ..., 0, b) by ks3_init_kernel
 };
@@ -259,24 +261,48 @@ __global__ void ks4_prepare_kernel(const int32_t *__restrict__ ks, i32x4 *__rest
     bmat[idx] = frag;
 }
 
-__global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
+// Rounded mask words a_i + 2^15 (keyswitch.jl:58-59; MUX: sum of two extracted samples, gates.jl:174) transposed
+// from the sample-major extracted rows into abar_t[i/4][sample] = 4 consecutive words: the MFMA kernel then reads
+// one aligned, fully coalesced 16 bytes per sample and stage instead of scattered 4-byte loads.
+__global__ __launch_bounds__(128) void ks4_digits_kernel(Ks4Args P, i32x4 *__restrict__ abar_t)
+{
+    __shared__ uint32_t tile[32][129];
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * 32, i0 = blockIdx.y * 128;
+    for (int g = 0; g < 32; g++) {
+        const int gg = min(g0 + g, P.G - 1);
+        const int32_t *r0 = P.ext + (size_t)P.e0[gg] * P.in_stride + P.in_off;
+        const int e1 = P.e1 ? P.e1[gg] : -1;
+        uint32_t v = (uint32_t)r0[i0 + tid];
+        if (e1 >= 0) v += (uint32_t)P.ext[(size_t)e1 * P.in_stride + P.in_off + i0 + tid];
+        tile[g][tid] = v + (1u << 15);
+    }
+    __syncthreads();
+    for (int k = tid; k < 32 * 32; k += 128) {
+        const int q = k >> 5, g = k & 31;              // consecutive threads -> consecutive samples
+        i32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; u++) o[u] = (int32_t)tile[g][4 * q + u];
+        abar_t[(size_t)(i0 / 4 + q) * P.Gpad + g0 + g] = o;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void keyswitch_kernel_v4(Ks4Args P)
 {
     constexpr int MT = 2;
+    // B fragments of 4 consecutive mask words, staged once per block (the 4 waves need the same ones):
+    // wave `pl` fetches byte-plane pl, everybody reads all four planes back from LDS.  Double-buffered.
+    __shared__ i32x4 bst[2][4][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int wt = blockIdx.y;
     const int gbase = (blockIdx.x * 4 + wave) * (32 * MT);
-    if (gbase >= P.G) return;
+    const bool wave_active = gbase < P.G;            // idle waves still help staging and take the barriers
 
-    const int32_t *row0[MT], *row1[MT];
+    // this lane's samples (row of the MFMA A operand): abar_t[stage][sample]
+    const i32x4 *ap[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int gg = min(gbase + mt * 32 + c, P.G - 1);
-        row0[mt] = P.ext + (size_t)P.e0[gg] * P.in_stride + P.in_off;
-        const int e1 = P.e1 ? P.e1[gg] : -1;
-        row1[mt] = e1 >= 0 ? P.ext + (size_t)e1 * P.in_stride + P.in_off : nullptr;
-    }
-    const uint32_t prec_offset = 1u << 15;                                   // 2^(32 - (1 + 2*8))   keyswitch.jl:58
+    for (int mt = 0; mt < MT; mt++) ap[mt] = P.abar_t + min(gbase + mt * 32 + c, P.Gpad - 1);
 
     i32x16 acc[MT][4];
 #pragma unroll
@@ -286,51 +312,60 @@ __global__ __launch_bounds__(256) void keyswitch_kernel_v4(Ks4Args P)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][pl][r] = 0;
 
-    const i32x4 *bp = P.bmat + (size_t)wt * 4 * 64 + lane;
     const size_t bstep = (size_t)P.wtiles * 4 * 64;                          // fragments per mask word i
-    i32x4 bcur[4], bnxt[4];
-#pragma unroll
-    for (int pl = 0; pl < 4; pl++) bcur[pl] = bp[pl * 64];
-
     const int i_begin = (int)blockIdx.z * (P.kN / P.kslices), i_end = i_begin + P.kN / P.kslices;
-    bp += (size_t)i_begin * bstep;
+    // this wave's plane of mask word i: bmat[i][wt][plane = wave][lane]
+    const i32x4 *bp = P.bmat + (size_t)i_begin * bstep + ((size_t)wt * 4 + wave) * 64 + lane;
+    const int stages = (i_end - i_begin) / 4;
+    i32x4 pre[4];
 #pragma unroll
-    for (int pl = 0; pl < 4; pl++) bcur[pl] = bp[pl * 64];
-    for (int i4 = i_begin; i4 < i_end; i4 += 4) {
-        // 4 consecutive mask words of this lane's samples (MUX: sum of two extracted samples, gates.jl:174)
-        uint32_t a4[MT][4];
+    for (int ii = 0; ii < 4; ii++) bst[0][ii][wave][lane] = bp[(size_t)ii * bstep];
+
+    // rounded mask words of this lane's samples for one stage (4 words), fetched one stage ahead
+    i32x4 a_cur[MT], a_nxt[MT];
+    auto load_a = [&](int i4, i32x4 (&a)[MT]) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MT; mt++) a[mt] = ap[mt][(size_t)(i4 >> 2) * P.Gpad];
+    };
+    load_a(i_begin, a_cur);
+
+    for (int st = 0; st < stages; st++) {
+        const bool more = st + 1 < stages;
+        if (more) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) pre[ii] = bp[(size_t)(4 * (st + 1) + ii) * bstep];
+            load_a(i_begin + 4 * (st + 1), a_nxt);
+        }
+        __syncthreads();     // stage st is visible; everybody is done reading the other buffer (stage st - 1)
+        if (wave_active) {
 #pragma unroll
             for (int ii = 0; ii < 4; ii++) {
-                uint32_t v = (uint32_t)row0[mt][i4 + ii];
-                if (row1[mt]) v += (uint32_t)row1[mt][i4 + ii];
-                a4[mt][ii] = v + prec_offset;                                // keyswitch.jl:59
-            }
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int i = i4 + ii;
-            const i32x4 *bn = bp + (size_t)((i + 1 < i_end ? i + 1 : i) - i_begin) * bstep;
-#pragma unroll
-            for (int pl = 0; pl < 4; pl++) bnxt[pl] = bn[pl * 64];
-            i32x4 afrag[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    // digit position j = 4h+q (0-based) occupies bits [30-2j, 31-2j]   keyswitch.jl:65-67
-                    const uint32_t d8 = (a4[mt][ii] >> (27 - 2 * (4 * h + q))) & 24u;   // 8 * digit
-                    afrag[mt][q] = (int32_t)(1u << d8);                      // one-hot byte
-                }
-#pragma unroll
-            for (int pl = 0; pl < 4; pl++)
+                i32x4 afrag[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    acc[mt][pl] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[mt], bcur[pl], acc[mt][pl], 0, 0, 0);
 #pragma unroll
-            for (int pl = 0; pl < 4; pl++) bcur[pl] = bnxt[pl];
+                    for (int q = 0; q < 4; q++) {
+                        // digit position j = 4h+q (0-based) occupies bits [30-2j, 31-2j]   keyswitch.jl:65-67
+                        const uint32_t d8 = ((uint32_t)a_cur[mt][ii] >> (27 - 2 * (4 * h + q))) & 24u;   // 8 * digit
+                        afrag[mt][q] = (int32_t)(1u << d8);                  // one-hot byte
+                    }
+#pragma unroll
+                for (int pl = 0; pl < 4; pl++) {
+                    const i32x4 bfrag = bst[st & 1][ii][pl][lane];
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+                        acc[mt][pl] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[mt], bfrag, acc[mt][pl], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) bst[(st + 1) & 1][ii][wave][lane] = pre[ii];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a_cur[mt] = a_nxt[mt];
         }
     }
+    if (!wave_active) return;
 
     // epilogue: C layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const int w = wt * 32 + c;

@@ -54,6 +54,7 @@ struct tfhe_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
     bool timing_valid = false;
     int64_t last_rotations = 0;
+    int ks_slices_large = 2;     // K-split of the MFMA keyswitch for large batches (tfhe_set_option("ks_slices", 1|2|4))
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
     int64_t br_small = 512;      // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never)
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
@@ -81,7 +82,7 @@ struct tfhe_ctx {
     int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
-    DevBuf bara, ext, map, io[4], margin;
+    DevBuf bara, ext, map, io[4], margin, abar;
     size_t margin_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations also record their rounding margin
@@ -208,7 +209,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
-    c->bara.release(); c->ext.release(); c->map.release(); c->margin.release();
+    c->bara.release(); c->ext.release(); c->map.release(); c->margin.release(); c->abar.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -413,18 +414,25 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     k.out = out;
     k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
     const int n1 = c->P.n + 1;
-    if (c->ks_variant == 4 && c->d_ks4) {
+    if (c->ks_variant == 4 && c->d_ks4 && k.kN % 128 == 0) {
         Ks4Args a4;
         a4.ext = ext; a4.bmat = (const i32x4 *)c->d_ks4; a4.e0 = e0; a4.e1 = e1; a4.dst = dst; a4.out = out;
         a4.n = c->P.n; a4.kN = k.kN; a4.G = (int)G; a4.wtiles = c->ks4_wtiles;
         a4.in_stride = k.kN + 1; a4.in_off = 0; a4.in_b = k.kN; a4.out_stride = n1; a4.out_off = 0; a4.out_b = c->P.n; a4.add_b = 1;
-        a4.kslices = (G <= 512 && k.kN % 64 == 0) ? 16 : 1;                 // small batches: split the mask words over 16 blocks
+        // split the mask words over several blocks, partial sums combined with exact integer atomics: 16 slices for
+        // small batches (latency), 2 for large ones (two waves per SIMD so that one wave's MFMAs overlap the other's
+        // A-fragment generation and LDS reads)
+        a4.kslices = (k.kN % 512 != 0) ? 1 : (G <= 512 ? 16 : c->ks_slices_large);
         if (a4.kslices > 1) {
             Ks3Args i3;
             i3.ext = ext; i3.e0 = e0; i3.e1 = e1; i3.dst = dst; i3.out = out; i3.kN = k.kN; i3.n = c->P.n;
             i3.in_stride = a4.in_stride; i3.in_b = a4.in_b; i3.out_stride = n1; i3.out_b = c->P.n;
             hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)G), dim3(256), 0, s, i3);
         }
+        a4.Gpad = (int)((G + 63) / 64 * 64);
+        HIP_TRY(c, c->abar.reserve((size_t)(k.kN / 4) * a4.Gpad * 16));
+        a4.abar_t = (const i32x4 *)c->abar.p;
+        hipLaunchKernelGGL(ks4_digits_kernel, dim3((unsigned)(a4.Gpad / 32), (unsigned)(k.kN / 128)), dim3(128), 0, s, a4, (i32x4 *)c->abar.p);
         hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((G + 255) / 256), (unsigned)c->ks4_wtiles, (unsigned)a4.kslices), dim3(256), 0, s, a4);
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
@@ -881,6 +889,10 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         a4.in_stride = ew; a4.in_b = NP * kN; a4.out_stride = nw; a4.out_b = NP * n;
         for (int p = 0; p < NP; p++) {
             a4.in_off = p * kN; a4.out_off = p * n; a4.add_b = (p == 0); a4.kslices = 1;
+            a4.Gpad = (int)((B + 63) / 64 * 64);
+            HIP_TRY(c, c->abar.reserve((size_t)(kN / 4) * a4.Gpad * 16));
+            a4.abar_t = (const i32x4 *)c->abar.p;
+            hipLaunchKernelGGL(ks4_digits_kernel, dim3((unsigned)(a4.Gpad / 32), (unsigned)(kN / 128)), dim3(128), 0, s, a4, (i32x4 *)c->abar.p);
             a4.bmat = (const i32x4 *)c->d_mk_ks4 + (size_t)p * c->mk_ks4_frags;
             hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((B + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
         }
@@ -955,6 +967,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
+    if (!strcmp(name, "ks_slices")) {
+        if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_slices must be 1, 2 or 4");
+        c->ks_slices_large = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "ks_variant")) {
