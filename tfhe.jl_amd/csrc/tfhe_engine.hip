@@ -1,12 +1,15 @@
-// tfhe_engine.hip — MI355X (gfx950) TFHE gate-bootstrapping engine: kernels, context, C ABI.
+// tfhe_engine.hip — MI355X (gfx950) TFHE gate-bootstrapping engine: context, key loading, launchers, C ABI
+// (include/tfhe_mi355x.h).  The kernels live in the three headers included below; this file is the only
+// translation unit.
 //
-// Pipeline of one batch call (tfhe_gates_batch*):
-//   prologue_kernel       gate affine prologue (gates.jl) + modulus switch (bootstrap.jl:74-75)
-//   blind_rotate_kernel   one wave per blind rotation, accumulator resident in LDS/registers for
-//                         all n CMUX steps (bootstrap.jl:19-59, tgsw.jl:99-129, polynomials.jl),
-//                         fused test-vector init and sample extraction (tlwe.jl:55-59)
-//   keyswitch_kernel      digit-gather-subtract keyswitch (keyswitch.jl:45-80), MUX add fused
-//   trivial_gates_kernel  NOT / CONSTANT / COPY (gates.jl:76-93)
+// Pipeline of one batch call (tfhe_gates_batch* / tfhe_gates_level):
+//   prologue_kernel          gate affine prologue (gates.jl) + modulus switch (bootstrap.jl:74-75)
+//   blind_rotate_kernel_*    accumulator resident in LDS for all n CMUX steps (bootstrap.jl:19-59, tgsw.jl:99-129,
+//                            polynomials.jl:106-132), fused test-vector init and sample extraction (tlwe.jl:55-59);
+//                            variant chosen by parameters and batch size (launch_blind_rotate)
+//   ks4_digits_kernel +      keyswitch (keyswitch.jl:45-80) as an exact int8 MFMA contraction, MUX add fused
+//   keyswitch_kernel_v4      (fallbacks: keyswitch_kernel_v3 / keyswitch_kernel)
+//   trivial_gates_kernel     NOT / CONSTANT / COPY (gates.jl:76-93)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
