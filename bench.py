@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--params", choices=["80", "128"], default="80")
+    ap.add_argument("--workload", choices=["nand", "mixed"], default="nand",
+                    help="nand: BASELINE config 2 per GPU (weak scaling, the default the driver runs); mixed: BASELINE config 3, "
+                         "65 536 i.i.d. {NAND, AND, OR, XOR, MUX} gates in total, sharded over the GPUs by rotation count (strong scaling)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-per-thread", type=int, default=24)
@@ -67,22 +70,41 @@ def main():
     eng = ck.engine(local_rank)
 
     # --- inputs: encryptions of i.i.d. uniform bits, seed 456 (+rank), uploaded before timing -------
-    B = args.gates
     n1 = params.lwe_size + 1
-    irng = np.random.default_rng(456 + rank)
-    bx, by = irng.integers(0, 2, B).astype(bool), irng.integers(0, 2, B).astype(bool)
-    hx, hy = tfhe.encrypt(irng, sk, bx).data, tfhe.encrypt(irng, sk, by).data
-    dx, dy = torch.from_numpy(hx).to(dev), torch.from_numpy(hy).to(dev)
+    if args.workload == "nand":
+        B = args.gates
+        irng = np.random.default_rng(456 + rank)
+        bx, by = irng.integers(0, 2, B).astype(bool), irng.integers(0, 2, B).astype(bool)
+        bz = np.zeros(B, bool)
+        ops = np.zeros(B, np.uint8)  # NAND
+        expect = ~(bx & by)
+        total_per_step = world * B
+    else:
+        from tfhe_jl_amd.sharding import shard_bounds
+        mrng = np.random.default_rng(789)                       # identical stream on every rank, then sliced
+        BT = 65536
+        names = ["NAND", "AND", "OR", "XOR", "MUX"]
+        sel = mrng.integers(0, 5, BT)
+        all_ops = np.array([tfhe.OPCODES[x] for x in names], np.uint8)[sel]
+        bits = [mrng.integers(0, 2, BT).astype(bool) for _ in range(3)]
+        s0, e0 = shard_bounds(all_ops, world)[rank]
+        ops, sel = all_ops[s0:e0], sel[s0:e0]
+        bx, by, bz = (b[s0:e0] for b in bits)
+        B = e0 - s0
+        expect = np.select([sel == 0, sel == 1, sel == 2, sel == 3, sel == 4], [~(bx & by), bx & by, bx | by, bx ^ by, np.where(bx, by, bz)])
+        total_per_step = BT
+        irng = np.random.default_rng(456 + rank)
+    hx, hy, hz = (tfhe.encrypt(irng, sk, b).data for b in (bx, by, bz))
+    dx, dy, dz = (torch.from_numpy(h).to(dev) for h in (hx, hy, hz))
     dout = torch.empty((B, n1), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * B, n1), dtype=torch.int32, device=dev) if n_gpus > 1 else None
-    ops = np.zeros(B, np.uint8)  # NAND
+    gathered = torch.empty((world * B, n1), dtype=torch.int32, device=dev) if (n_gpus > 1 and args.workload == "nand") else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     br_ms, ks_ms = [], []
 
     def step(record):
-        eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), 0, dout.data_ptr(), B, stream)
-        if n_gpus > 1 and not args.no_gather:
+        eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
+        if gathered is not None and not args.no_gather:
             dist.all_gather_into_tensor(gathered, dout)
         if record:
             br_ms.append(eng.last_timing_ms(0))   # HIP events on `stream` around the blind-rotate kernel
@@ -108,14 +130,14 @@ def main():
 
     # --- correctness of what was just timed (not timed itself) ---------------------------------------
     out = dout.cpu().numpy()
-    ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), ~(bx & by)))
+    ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), expect))
 
     result = None
     if rank == 0:
         rotations_per_step = eng.last_rotation_count()
         br_avg_s = float(np.mean(br_ms)) * 1e-3
         achieved = rotations_per_step * BR_BYTES[args.params] / br_avg_s
-        total_gates = world * B * args.steps
+        total_gates = total_per_step * args.steps
         result = {
             "metric": "bootstrapped gates/sec (whole node), N=1024",
             "value": total_gates / elapsed,
@@ -126,18 +148,19 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_bootstrap_amortised": elapsed / args.steps * 1e3 / B,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.workload == "nand" else "strong",
             "vs_baseline": None,
             "dtype": "int32 torus / f64 transform",
             "data": "synthetic: oracle-independent numpy keygen (seed 123), encryptions of uniform random bits (seed 456)",
             "config": {
-                "workload": f"batch of {B} independent gate_nand() bootstraps per GPU, tfhe_parameters_{args.params} "
+                "workload": (f"batch of {B} independent gate_nand() bootstraps per GPU" if args.workload == "nand" else
+                             f"mixed gate stream (NAND/AND/OR/XOR/MUX), 65536 gates in total, {B} on rank 0") + f", tfhe_parameters_{args.params} "
                             f"(n={params.lwe_size}, N=1024, k=1, l={params.bs_decomp_length}, Bg=2^{params.bs_log2_base}, "
                             f"ks t={params.ks_decomp_length}, base 2^{params.ks_log2_base})",
                 "gates_per_gpu_per_step": B,
-                "result_gather": "rccl all_gather" if (n_gpus > 1 and not args.no_gather) else "none",
+                "result_gather": "rccl all_gather" if (gathered is not None and not args.no_gather) else "none",
             },
-            "outputs_decrypt_to_nand": ok_decrypt,
+            "outputs_decrypt_correctly": ok_decrypt,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "blind_rotate_kernel_v3",
@@ -152,7 +175,7 @@ def main():
                 "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
             },
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "nand":
             result["cpu_baseline"] = cpu_baseline(tfhe, params, ck, hx, hy, out, args)
         print(json.dumps(result), flush=True)
     if n_gpus > 1:
@@ -160,7 +183,7 @@ def main():
         dist.destroy_process_group()
     ck.close()
     if not ok_decrypt:
-        sys.exit("bench.py: GPU outputs did not decrypt to NAND")
+        sys.exit("bench.py: GPU outputs did not decrypt to the gates' truth values")
 
 
 def traffic_from_profiles(kernel_substr, units_per_launch):
