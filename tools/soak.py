@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Soak run: random batch sizes and opcode mixes against the oracle (every output word for small batches, a random
+sample for large ones) plus decrypt checks, alternating the host-buffer API and the wire-table level API."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import tfhe_jl_amd as tfhe, oracle
+from conftest import KeySet
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+K = KeySet(tfhe, oracle, tfhe.tfhe_parameters_80())
+eng = K.ck.engine(0)
+rng = np.random.default_rng(2026)
+names = list(tfhe.OPCODES)
+truth = {"NAND": lambda x, y, z: ~(x & y), "OR": lambda x, y, z: x | y, "AND": lambda x, y, z: x & y, "XOR": lambda x, y, z: x ^ y,
+         "XNOR": lambda x, y, z: ~(x ^ y), "NOT": lambda x, y, z: ~x, "NOR": lambda x, y, z: ~(x | y), "ANDNY": lambda x, y, z: ~x & y,
+         "ANDYN": lambda x, y, z: x & ~y, "ORNY": lambda x, y, z: ~x | y, "ORYN": lambda x, y, z: x | ~y,
+         "MUX": lambda x, y, z: np.where(x, y, z), "CONST0": lambda x, y, z: np.zeros_like(x), "CONST1": lambda x, y, z: np.ones_like(x),
+         "COPY": lambda x, y, z: x}
+t0 = time.time()
+for it in range(iters):
+    B = int(rng.choice([1, 2, 7, 64, 100, 511, 512, 513, 1000, 2049, 3000]))
+    sel = rng.integers(0, len(names), B)
+    ops = np.array([tfhe.OPCODES[names[s]] for s in sel], np.uint8)
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
+    if it % 2 == 0:
+        got = eng.gates(ops, *ins)
+    else:                                    # same gates through the wire table, one level
+        eng.wires_alloc(4 * B)
+        eng.wires_upload(0, np.concatenate(ins))
+        idx = np.arange(B, dtype=np.int32)
+        eng.gates_level(ops, idx, idx + B, idx + 2 * B, idx + 3 * B)
+        got = eng.wires_download(3 * B, B)
+    want_bits = np.zeros(B, bool)
+    for k, nm in enumerate(names):
+        m = sel == k
+        if m.any():
+            want_bits[m] = truth[nm](bits[0][m], bits[1][m], bits[2][m])
+    assert np.array_equal(tfhe.decrypt(K.sk, got), want_bits), f"iter {it}: decrypt mismatch"
+    samp = np.arange(B) if B <= 128 else rng.choice(B, 128, replace=False)
+    want = K.oracle.gates(ops[samp], *[a[samp] for a in ins], nthreads=32)
+    assert np.array_equal(got[samp], want), f"iter {it}: word mismatch"
+    print(f"iter {it:3d} B={B:5d} ok ({'level' if it % 2 else 'batch'})", flush=True)
+print(f"soak ok: {iters} iterations in {time.time() - t0:.1f} s")
