@@ -72,5 +72,6 @@ def host_sim():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     lib = C.CDLL(so)
     lib.sim_blind_rotate.restype = C.c_double
+    lib.sim_blind_rotate_v3.restype = C.c_double
     lib.sim_freq_of.restype = C.c_int32
     return lib

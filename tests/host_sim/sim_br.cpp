@@ -15,9 +15,14 @@ namespace {
 
 struct HostTables {
     std::vector<cplx> buf;
+    std::vector<cplx> full;   // tw1 | tw2 | twist | tw1f, as the engine builds them (fill_tables)
     Tables T;
+    Tables Tfull;
     HostTables()
     {
+        full.resize(kTableElems);
+        fill_tables<long double>(full.data(), [](long double a) { return cosl(a); }, [](long double a) { return sinl(a); });
+        Tfull = tables_from(full.data());
         const long double pi = 3.14159265358979323846264338327950288L;
         buf.resize(512 + 64 + 512);
         for (int q = 0; q < 8; q++)
@@ -162,6 +167,75 @@ double sim_blind_rotate(const int32_t *bara, int32_t n, int32_t L, int32_t log2_
             else ext[kN - j] = (int32_t)(0u - (uint32_t)acc[0][l][m]);
         }
     ext[kN] = acc[1][0][0];
+    return worst;
+}
+
+// blind_rotate_kernel_v3's lane code (the shipped path): rotate_sub2 / load_digits2 / tw1f-folded passes /
+// untwist_add2, lane by lane.  bk spectra in engine order as sim_bk_prepare produces them.
+double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t log2_base, int32_t mu,
+                           const double *bk_spec, int32_t *ext)
+{
+    const Tables &T = tables().Tfull;
+    const Gadget g = make_gadget(L, log2_base);
+    const int32_t xormask = gadget_xor_mask(L, log2_base);
+    const int K1 = 2;
+    std::vector<int32_t> acc_lds(K1 * kN);
+    const cplx *bk = reinterpret_cast<const cplx *>(bk_spec);
+    static LaneTw tw[64];
+    for (int l = 0; l < 64; l++) load_lane_tw(l, T, tw[l]);
+    double worst = 0.0;
+    const int barb = bara[n] & (2 * kN - 1);
+    for (int j = 0; j < kN; j++) {
+        acc_lds[j] = 0;
+        const int idx = (j + barb) & (2 * kN - 1);
+        acc_lds[kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)mu) : mu;
+    }
+    std::vector<cplx> xch(kXchElems);
+    for (int i = 0; i < n; i++) {
+        const int a = bara[i] & (2 * kN - 1);          // no skip for a == 0: the step must add exactly zero
+        const cplx *bki = bk + (size_t)i * (L * K1 * K1 * kM);
+        static Regs out[2];
+        for (int c = 0; c < K1; c++)
+            for (int l = 0; l < 64; l++)
+                for (int q = 0; q < 8; q++) out[c][l][q] = mk(0.0, 0.0);
+        for (int c = 0; c < K1; c++) {
+            static int32_t temp[64][16];
+            for (int l = 0; l < 64; l++) {
+                int32_t cur[16];
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + l + 64 * m];
+                rotate_sub2(l, a, acc_lds.data() + c * kN, cur, g.offset, xormask, temp[l]);
+            }
+            for (int p = 1; p <= L; p++) {
+                Regs x;
+                for (int l = 0; l < 64; l++) { load_digits2(temp[l], p, log2_base, x[l]); fwd2_pass_a(x[l], tw[l]); x1_store_a(l, x[l], xch.data()); }
+                for (int l = 0; l < 64; l++) x1_load_b(l, x[l], xch.data());
+                for (int l = 0; l < 64; l++) { fwd2_pass_b(x[l], tw[l]); x2_store(l, x[l], xch.data()); }
+                for (int l = 0; l < 64; l++) x2_load(l, x[l], xch.data());
+                for (int l = 0; l < 64; l++) {
+                    fwd_pass_c(x[l]);
+                    const cplx *kp = bki + (size_t)((p - 1) * K1 + c) * K1 * kM + l;
+                    for (int co = 0; co < K1; co++)
+                        for (int k2 = 0; k2 < 8; k2++) out[co][l][k2] = cfma(x[l][k2], kp[(co * 8 + k2) * 64], out[co][l][k2]);
+                }
+            }
+        }
+        for (int co = 0; co < K1; co++) {
+            for (int l = 0; l < 64; l++) { inv_pass_c(out[co][l]); x2_store(l, out[co][l], xch.data()); }
+            for (int l = 0; l < 64; l++) x2_load(l, out[co][l], xch.data());
+            for (int l = 0; l < 64; l++) { inv2_pass_b(out[co][l], tw[l]); x1_store_b(l, out[co][l], xch.data()); }
+            for (int l = 0; l < 64; l++) x1_load_a(l, out[co][l], xch.data());
+            for (int l = 0; l < 64; l++) {
+                inv2_pass_a(out[co][l], tw[l]);
+                int32_t accr[16];
+                for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + l + 64 * m];
+                untwist_add2<true>(out[co][l], accr, &worst);
+                for (int m = 0; m < 16; m++) acc_lds[co * kN + l + 64 * m] = accr[m];
+            }
+        }
+    }
+    ext[0] = acc_lds[0];
+    for (int j = 1; j < kN; j++) ext[kN - j] = (int32_t)(0u - (uint32_t)acc_lds[j]);
+    ext[kN] = acc_lds[kN];
     return worst;
 }
 

@@ -52,3 +52,9 @@ def test_blind_rotate_lane_code_matches_oracle(host_sim, orc, tfhe, l, beta):
                                            _p(spec), _p(ext))
         assert np.array_equal(ext, want)
         assert margin < 0.25
+        # the shipped kernel's lane code (blind_rotate_kernel_v3: folded twiddles, bit-field digits, no zero-skip)
+        ext3 = np.zeros(N + 1, np.int32)
+        margin3 = host_sim.sim_blind_rotate_v3(_p(bara), C.c_int32(n), C.c_int32(l), C.c_int32(beta), C.c_int32(mu),
+                                               _p(spec), _p(ext3))
+        assert np.array_equal(ext3, want)
+        assert margin3 < 0.25
