@@ -128,6 +128,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # --- "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1), outside the timed region -------
+    single_ms = None
+    if rank == 0 and args.workload == "nand":
+        one = np.zeros(1, np.uint8)
+        o1 = torch.empty((1, n1), dtype=torch.int32, device=dev)
+        lat = []
+        for it in range(25):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            eng.gates_dev(one, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), o1.data_ptr(), 1, stream)
+            torch.cuda.synchronize(dev)
+            lat.append(time.perf_counter() - t1)
+        single_ms = float(np.median(lat[5:])) * 1e3
+        assert torch.equal(o1[0], dout[0]), "single-gate result differs from the batched one"
+
     # --- correctness of what was just timed (not timed itself) ---------------------------------------
     out = dout.cpu().numpy()
     ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), expect))
@@ -147,6 +162,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_bootstrap_amortised": elapsed / args.steps * 1e3 / B,
+            "ms_per_bootstrap_single_gate": single_ms,
             "higher_is_better": True,
             "scaling": "weak" if args.workload == "nand" else "strong",
             "vs_baseline": None,
