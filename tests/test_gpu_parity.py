@@ -283,3 +283,20 @@ def test_gpu_rounding_margin(tfhe, keys80, eng80, keys128, eng128):
         eng.set_option("measure_margin", 0)
         assert np.array_equal(got, ref)
         assert 0.0 < margin < 0.25, margin
+
+
+def test_nonstandard_keyswitch_shape_uses_fallback(tfhe, orc):
+    """A keyswitch decomposition other than the shipped (t = 8, base 4) one — here t = 5, base 8 — takes the generic
+    gather kernel (keyswitch_kernel) and must still match the oracle (keyswitch.jl:45-80 for any base / length)."""
+    from conftest import KeySet
+    p = tfhe.SchemeParameters(40, 1 / 2**15, 1024, 1, 2, 10, 9e-9, 5, 3, 1 / 2**15, 1)
+    K = KeySet(tfhe, orc, p, seed=53)
+    assert K.ck.keyswitch_key.shape == (1024, 5, 7, 41)
+    eng = K.ck.engine(0)
+    x = tfhe.encrypt(K.rng, K.sk, [True, False, True, False, True]).data
+    y = tfhe.encrypt(K.rng, K.sk, [True, True, False, False, True]).data
+    z = tfhe.encrypt(K.rng, K.sk, [False, True, True, False, False]).data
+    for name in ("NAND", "MUX"):
+        ops = np.full(5, tfhe.OPCODES[name], np.uint8)
+        assert np.array_equal(eng.gates(ops, x, y, z), K.oracle.gates(ops, x, y, z, nthreads=5))
+    K.ck.close()
