@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/tfhe_mi355x.h"
+#include <type_traits>
+
 #include "br_core.hpp"
 
 using namespace tfhe;
@@ -810,6 +812,16 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 // Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
 constexpr int kN2 = 2048;
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the body needs I as a constant expression)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
 {
     constexpr double T[17] = {1.0, 0.99518472667219692873, 0.98078528040323043058, 0.95694033573220882438,
@@ -844,7 +856,6 @@ __device__ __forceinline__ cplx fwd_in_2048(double lo, double hi, double s2, dou
     return mk(re * cr - im * sr, -(re * sr + im * cr));          // (re - i im) e^{-i theta}
 }
 
-template <int MM>
 __device__ __forceinline__ void rotate_sub_2048(int lane, int a, const int32_t *acc_lds, int32_t offset, int32_t xormask, int32_t (&temp)[32])
 {
     const int base = (lane - a) & (2 * kN2 - 1);
@@ -911,19 +922,17 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
             {
                 int a_here = a;
                 asm volatile("" : "+v"(a_here));
-                rotate_sub_2048<0>(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
+                rotate_sub_2048(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
             }
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
                 cplx x[8];
-#define FWD_IN(R)                                                                                          \
-    {                                                                                                      \
-        const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);            \
-        const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);      \
-        x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);    \
-    }
-                FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
-#undef FWD_IN
+                static_for<0, 8>([&](auto rc) {
+                    constexpr int R = decltype(rc)::value;
+                    const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);
+                    const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
+                    x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
+                });
                 fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
 #pragma unroll
@@ -949,22 +958,20 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
             __syncthreads();
             // wave 0: (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024
             // wave 1: (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
-#define COMBINE(R)                                                                                         \
-    {                                                                                                      \
-        const cplx al = wave1 ? oth[R] : out[d][R], be = wave1 ? out[d][R] : oth[R];                       \
-        const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);           /* e_r = e^{-i pi r/8} */      \
-        const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er; /* conj(beta) e_r: re, im */  \
-        const double vr = wave1 ? al.x - br : al.x + br;                     /* conj(alpha) = (al.x, -al.y) */ \
-        const double vi = wave1 ? -al.y - bi : -al.y + bi;                                                 \
-        const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R); \
-        const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;                                       \
-        const int jlo = lane + 64 * R + (wave1 ? 512 : 0);                                                 \
-        int32_t *ap = acc_lds + d * kN2;                                                                   \
-        ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));                           \
-        ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));             \
-    }
-            COMBINE(0) COMBINE(1) COMBINE(2) COMBINE(3) COMBINE(4) COMBINE(5) COMBINE(6) COMBINE(7)
-#undef COMBINE
+            static_for<0, 8>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const cplx al = wave1 ? oth[R] : out[d][R], be = wave1 ? out[d][R] : oth[R];
+                const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
+                const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er;    // conj(beta) e_r
+                const double vr = wave1 ? al.x - br : al.x + br;                        // conj(alpha) = (al.x, -al.y)
+                const double vi = wave1 ? -al.y - bi : -al.y + bi;
+                const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R);
+                const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;
+                const int jlo = lane + 64 * R + (wave1 ? 512 : 0);
+                int32_t *ap = acc_lds + d * kN2;
+                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));
+                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));
+            });
         }
         __syncthreads();
     }
@@ -996,14 +1003,12 @@ __global__ __launch_bounds__(128) void bk_prepare_kernel_n2048(const int32_t *__
     if (tid < 64) tw2_lds[tid] = tw2[tid];
     __syncthreads();
     cplx x[8];
-#define FWD_IN(R)                                                                                          \
-    {                                                                                                      \
-        const double lo = (double)poly[lane + 64 * R], l2 = (double)poly[lane + 64 * R + 512];             \
-        const double hi = (double)poly[lane + 64 * R + 1024], h2 = (double)poly[lane + 64 * R + 1536];     \
-        x[R] = fwd_in_2048<R>(lo, hi, l2 - h2, l2 + h2, sg, wave1);                                        \
-    }
-    FWD_IN(0) FWD_IN(1) FWD_IN(2) FWD_IN(3) FWD_IN(4) FWD_IN(5) FWD_IN(6) FWD_IN(7)
-#undef FWD_IN
+    static_for<0, 8>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const double lo = (double)poly[lane + 64 * R], l2 = (double)poly[lane + 64 * R + 512];
+        const double hi = (double)poly[lane + 64 * R + 1024], h2 = (double)poly[lane + 64 * R + 1536];
+        x[R] = fwd_in_2048<R>(lo, hi, l2 - h2, l2 + h2, sg, wave1);
+    });
     fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
     const double s = 1.0 / 1024.0;
 #pragma unroll
