@@ -40,7 +40,8 @@ def main():
                          "65 536 i.i.d. {NAND, AND, OR, XOR, MUX} gates in total, sharded over the GPUs by rotation count (strong scaling)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-per-thread", type=int, default=24)
+    ap.add_argument("--cpu-sample-per-thread", type=int, default=8,
+                    help="gates per host thread in the cpu_baseline sample (8 x 128 threads x ~30 ms = ~30 s of CPU work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -234,7 +235,7 @@ def cpu_baseline(tfhe, params, ck, hx, hy, gpu_out, args):
     o.load_bootstrap_key(ck.bootstrap_key)
     o.load_keyswitch_key(ck.keyswitch_key)
     threads = oracle.max_threads()
-    S = min(hx.shape[0], args.cpu_sample_per_thread * threads)
+    S = min(hx.shape[0], max(64, args.cpu_sample_per_thread * threads))
     ops = np.zeros(S, np.uint8)
     t0 = time.perf_counter()
     want = o.gates(ops, hx[:S], hy[:S], nthreads=threads)
