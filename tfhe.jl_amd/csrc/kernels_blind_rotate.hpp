@@ -394,10 +394,8 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
             }
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
-                cplx x[8];
-                load_digits2(temp, p + 1, beta, x);
-                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
-                // key polys for this transform (mk_internals.jl:371-385)
+                // key polys for this transform (mk_internals.jl:371-385); the two every source needs are requested
+                // before the FFT (small batches leave one wave per SIMD: nobody else hides an L2 round trip)
                 const cplx *k_party, *k_body, *k_other = nullptr;
                 if (s < NP) {
                     k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
@@ -407,18 +405,22 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
                     k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
                     k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
                 }
+                cplx kpa[8], kbo[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) { kpa[k2] = k_party[k2 * 64]; kbo[k2] = k_body[k2 * 64]; }
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
                 cplx kv[8];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_party[k2 * 64];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kv[k2], out[PARTY][k2]);
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_body[k2 * 64];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kv[k2], out[NP][k2]);
                 if (s < NP && s != PARTY) {
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_other[k2 * 64];
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kpa[k2], out[PARTY][k2]);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kbo[k2], out[NP][k2]);
+                if (s < NP && s != PARTY) {
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) out[s < NP ? s : 0][k2] = cfma(x[k2], kv[k2], out[s < NP ? s : 0][k2]);
                 }
@@ -438,7 +440,7 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
 }
 
 template <int L>
-__global__ __launch_bounds__(64, 2) void mk_blind_rotate_kernel(MkBrArgs P)
+__global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 {
     constexpr int NP = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -562,24 +564,25 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
                 }
 #pragma unroll 1
                 for (int p = 0; p < L; p++) {
+                    const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]
+                    const cplx *k_body = key + (size_t)(is_body ? 2 * L * NP + p : p * NP + s) * kM;                 // c0[p] | x[p, s]
+                    cplx kpa[8], kbo[8];                      // requested before the FFT (see mk_party_steps)
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) { kpa[k2] = k_party[k2 * 64]; kbo[k2] = k_body[k2 * 64]; }
                     cplx x[8];
                     load_digits2(temp, p + 1, beta, x);
                     fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
-                    const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]
-                    const cplx *k_body = key + (size_t)(is_body ? 2 * L * NP + p : p * NP + s) * kM;                 // c0[p] | x[p, s]
                     cplx kv[8];
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_party[k2 * 64];
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cfma(x[k2], kv[k2], o_party[k2]);
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_body[k2 * 64];
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cfma(x[k2], kv[k2], o_body[k2]);
                     if (has_self) {
                         const cplx *k_self = key + (size_t)(L * NP + p * NP + party) * kM;                           // y[p, party]
 #pragma unroll
                         for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_self[k2 * 64];
+                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cfma(x[k2], kpa[k2], o_party[k2]);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cfma(x[k2], kbo[k2], o_body[k2]);
+                    if (has_self) {
 #pragma unroll
                         for (int k2 = 0; k2 < 8; k2++) o_self[k2] = cfma(x[k2], kv[k2], o_self[k2]);
                     }
@@ -762,15 +765,18 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
             }
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
+                cplx kfirst[8];                               // co = 0 requested before the FFT
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) kfirst[k2] = kp[k2 * 64];
                 cplx x[8];
                 load_digits2(temp, p + 1, beta, x);
                 fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
-                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
 #pragma unroll
                 for (int co = 0; co < K1; co++) {
                     cplx kv[8];
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(co * 8 + k2) * 64];
+                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = co == 0 ? kfirst[k2] : kp[(co * 8 + k2) * 64];
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
                 }
