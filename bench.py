@@ -124,6 +124,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
     if n_gpus > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -150,7 +151,6 @@ def main():
 
     result = None
     if rank == 0:
-        rotations_per_step = eng.last_rotation_count()
         br_avg_s = float(np.mean(br_ms)) * 1e-3
         achieved = rotations_per_step * BR_BYTES[args.params] / br_avg_s
         total_gates = total_per_step * args.steps
