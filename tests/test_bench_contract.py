@@ -1,0 +1,31 @@
+"""bench.py contract: one JSON line with the required fields and self-consistent roofline numbers
+(a regression here — e.g. the rotation count read after a later 1-gate call — silently corrupts `roofline.frac`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_json_line_is_consistent():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gates", "512",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["outputs_decrypt_correctly"] is True
+    rf = d["roofline"]
+    assert rf["units_per_launch"] == 512 and rf["bytes_per_unit"] == 16384000
+    assert abs(rf["achieved"] - 512 * 16384000 / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.01 < rf["frac"] < 1.5
+    assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert 0.1 < d["ms_per_bootstrap_single_gate"] < 50
