@@ -126,7 +126,8 @@ int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *i
 
 /* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`
  * (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host except
- * for the upload of the B opcode bytes; results are ordered on `stream`. */
+ * for the upload of the B opcode bytes; results are ordered on `stream`.  The context's workspaces are shared by
+ * all calls: a call on a different stream than the previous one first waits for that previous stream. */
 int32_t tfhe_gates_batch_dev(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *d_in0,
                              const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, int64_t B,
                              void *stream);

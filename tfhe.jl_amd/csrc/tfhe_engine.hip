@@ -55,6 +55,8 @@ struct tfhe_ctx {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
+    hipStream_t last_stream = nullptr;   // stream of the previous batch call: the workspaces are shared, so a call on a
+                                         // different stream first waits for the previous stream (enter_stream)
     bool timing_valid = false;
     int64_t last_rotations = 0;
     int ks_slices_large = 2;     // K-split of the MFMA keyswitch for large batches (tfhe_set_option("ks_slices", 1|2|4))
@@ -459,6 +461,15 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     return TFHE_OK;
 }
 
+// Workspaces (bara, ext, abar, map, margin) are per context: work enqueued on another stream must have finished
+// before a call on stream `s` reuses them.
+static int32_t enter_stream(tfhe_ctx *c, hipStream_t s)
+{
+    if (c->last_stream && c->last_stream != s) HIP_TRY(c, hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    return TFHE_OK;
+}
+
 static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
 {
     if (c->map_pending) {   // the previous call's H2D copy of the staging block must have been consumed
@@ -479,6 +490,10 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
                          const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, const int32_t *ia, const int32_t *ib,
                          const int32_t *ic, const int32_t *io, hipStream_t s)
 {
+    {
+        const int32_t rc0 = enter_stream(c, s);
+        if (rc0) return rc0;
+    }
     // classify gates: rotations (R), keyswitches (G), trivial (T)
     size_t R = 0, G = 0, Tn = 0;
     bool need1 = false, need2 = false, need0 = false;
@@ -696,6 +711,7 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
     if (!c->have_bk || (with_keyswitch && !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "bootstrap_batch: key not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
     const int n = c->P.n, kNn = c->P.k * c->P.N;
     const size_t in_bytes = (size_t)B * (n + 1) * 4;
     HIP_TRY(c, c->io[0].reserve(in_bytes));
@@ -741,6 +757,7 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     if (!c->have_ks) return c->set_err(TFHE_ERR_NO_KEY, "keyswitch_batch: keyswitch key not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
     const int n = c->P.n, kNn = c->P.k * c->P.N;
     const size_t in_bytes = (size_t)B * (kNn + 1) * 4, out_bytes = (size_t)B * (n + 1) * 4;
     HIP_TRY(c, c->ext.reserve(in_bytes));
@@ -837,6 +854,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     if (!c->have_mk_bk || !c->have_mk_ks) return c->set_err(TFHE_ERR_NO_KEY, "mk_gate_nand_batch: multi-key keys not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
     const int NP = c->mk_parties, n = c->P.n, nw = NP * n + 1, ew = NP * kN + 1;
     const size_t bytes = (size_t)B * nw * 4;
     for (int i = 0; i < 2; i++) {
