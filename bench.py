@@ -58,11 +58,20 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    # Rehearsal mode for a one-GPU box (tests/test_bench_contract.py): TFHE_BENCH_SHARE_GPU=1 puts every rank on
+    # device 0 and uses gloo for the barrier / max-reduce (RCCL refuses two ranks on one device); no result gather.
+    share_gpu = os.environ.get("TFHE_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+        args.no_gather = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if n_gpus > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # --- keys: identical on every rank (seed 123), replicated per GPU ------------------------------
     params = tfhe.tfhe_parameters_80() if args.params == "80" else tfhe.tfhe_parameters_128()
@@ -126,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
     if n_gpus > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -29,3 +29,25 @@ def test_bench_json_line_is_consistent():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.01 < rf["frac"] < 1.5
     assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert 0.1 < d["ms_per_bootstrap_single_gate"] < 50
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_launch_rehearsal():
+    """The driver's multi-GPU launch line with 2 ranks, rehearsed on one GPU (TFHE_BENCH_SHARE_GPU=1: both ranks on
+    device 0, gloo instead of RCCL for barrier / max-reduce, no gather): rank 0 prints one whole-job JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TFHE_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--gates", "512"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]   # whole-job aggregate
+    assert d["outputs_decrypt_correctly"] is True
