@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Soak run: random batch sizes and opcode mixes against the oracle (every output word for small batches, a random
+"""Soak run (lives under tests/ because it uses the oracle as the checker; not collected by pytest — run it as
+`python tests/soak_run.py [iterations]` on a GPU box): random batch sizes and opcode mixes against the oracle (every output word for small batches, a random
 sample for large ones) plus decrypt checks, alternating the host-buffer API and the wire-table level API."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))                    # tests/ (conftest.KeySet)
 import tfhe_jl_amd as tfhe, oracle
 from conftest import KeySet
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
