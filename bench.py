@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — bootstrapped gates/sec on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--gates B] [--params 80|128]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--gates B] [--params 80|128] [--workload nand|mixed]
 
 One "step" = one pass of the hot path (gate prologue -> blind rotate -> extract -> keyswitch) over one
 batch of B = 4096 independent NAND gates per GPU (BASELINE config 2: "batch of 4096 independent
 gate_nand() bootstraps, N=1024, 1xMI355X"), inputs resident in HBM before the timed region.
-N > 1: one process per GPU (torch.distributed / RCCL), every rank runs its own 4096-gate shard
-(weak scaling: independent gates, replicated keys) and the shards' results are gathered with one RCCL
-all_gather per step — the only collective.  Rank 0 prints ONE JSON line.
+
+N > 1, either launch style gives the same one-process-per-GPU job (torch.distributed over RCCL):
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's line), or
+  * plain `python bench.py --gpus N`: this process then only starts N fresh rank processes itself — before it
+    imports torch or touches a GPU — relays rank 0's JSON line and exits non-zero if any rank failed.
+Every rank runs its own shard (nand: 4096 gates per GPU, weak scaling; mixed: BASELINE config 3, 65 536 gates
+in total cut into rotation-balanced shards, strong scaling) with no communication during compute; the shards'
+results are gathered to rank 0 with ONE RCCL gather per step — the only collective.  Rank 0 prints ONE JSON line.
+
+`--fanout` is the other way to use N GPUs: ONE process, ONE multi-device context (tfhe_ctx_create_multi) whose
+tfhe_gates_batch splits the host batch over the GPUs inside the library (what a Julia caller gets).
 """
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,14 +32,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BR_BYTES = {  # algorithmic key bytes per blind rotation: n*l*(k+1)^2*N*4
-    "80": 500 * 2 * 4 * 1024 * 4,     # 16 384 000
-    "128": 630 * 3 * 4 * 1024 * 4,    # 30 965 760
-}
-HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+FP64_VALU_PEAK = 78.6e12   # FLOP/s vector FP64 at the 2.4 GHz maximum clock (256 CUs x 4 SIMDs x 32 FLOP/clk)
+MAX_CLOCK_MHZ = 2400.0
 
 
-def main():
+def br_bytes(p):
+    """Algorithmic key bytes per blind rotation, n*l*(k+1)^2*N*4 (canonical Int32 key, no reuse credited)."""
+    return p.lwe_size * p.bs_decomp_length * (p.tlwe_mask_size + 1) ** 2 * p.tlwe_polynomial_degree * 4
+
+
+def br_flops(p):
+    """Algorithmic FP64 flops per blind rotation (SURVEY §8d "secondary"): per CMUX step (k+1)(l+1) transforms of
+    5 M log2 M flops (M = N/2) plus (k+1)^2 l M complex multiply-adds of 8 flops; n steps."""
+    M = p.tlwe_polynomial_degree // 2
+    k1, l = p.tlwe_mask_size + 1, p.bs_decomp_length
+    return p.lwe_size * (k1 * (l + 1) * 5 * M * int(np.log2(M)) + k1 * k1 * l * M * 8)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -39,18 +61,52 @@ def main():
                     help="nand: BASELINE config 2 per GPU (weak scaling, the default the driver runs); mixed: BASELINE config 3, "
                          "65 536 i.i.d. {NAND, AND, OR, XOR, MUX} gates in total, sharded over the GPUs by rotation count (strong scaling)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather (N > 1)")
+    ap.add_argument("--fanout", action="store_true",
+                    help="one process, one multi-device context: the library splits a host batch over --gpus devices itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the in-kernel clock / rounding-margin run and the PCIe-inclusive loop")
     ap.add_argument("--cpu-sample-per-thread", type=int, default=8,
                     help="gates per host thread in the cpu_baseline sample (8 x 128 threads x ~30 ms = ~30 s of CPU work)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.  Runs before torch or the
+    HIP library is imported, so this parent never touches a GPU; children are fresh processes (no exec of a process
+    that has initialised the GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.exit(f"bench.py: rank(s) failed: {bad}")
+    sys.exit(0)
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None and not args.fanout:
+        spawn_ranks(args.gpus)          # never returns
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-    n_gpus = world
+    world = int(world_env or "1")
+    if args.fanout:
+        if world != 1:
+            sys.exit("bench.py --fanout is a single-process mode")
+    elif args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_gpus = args.gpus
 
     import torch
     import torch.distributed as dist
@@ -58,15 +114,15 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
-    # Rehearsal mode for a one-GPU box (tests/test_bench_contract.py): TFHE_BENCH_SHARE_GPU=1 puts every rank on
-    # device 0 and uses gloo for the barrier / max-reduce (RCCL refuses two ranks on one device); no result gather.
+    # Rehearsal mode for a one-GPU box (tests/test_bench_contract.py): TFHE_BENCH_SHARE_GPU=1 puts every rank (or every
+    # device context of --fanout) on device 0 and uses gloo for the barrier / max-reduce / gather (RCCL refuses two
+    # ranks on one device).
     share_gpu = os.environ.get("TFHE_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
-        args.no_gather = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if n_gpus > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -77,27 +133,33 @@ def main():
     params = tfhe.tfhe_parameters_80() if args.params == "80" else tfhe.tfhe_parameters_128()
     krng = np.random.default_rng(123)
     sk, ck = tfhe.make_key_pair(krng, params)
-    eng = ck.engine(local_rank)
+    if args.fanout:
+        eng = ck.engine([0] * n_gpus if share_gpu else list(range(n_gpus)))
+    else:
+        eng = ck.engine(local_rank)
 
     # --- inputs: encryptions of i.i.d. uniform bits, seed 456 (+rank), uploaded before timing -------
     n1 = params.lwe_size + 1
+    from tfhe_jl_amd.sharding import gather_to_root, shard_bounds
+    parts = 1 if args.fanout else world          # shards handled by separate processes
     if args.workload == "nand":
-        B = args.gates
+        B = args.gates * (n_gpus if args.fanout else 1)
         irng = np.random.default_rng(456 + rank)
         bx, by = irng.integers(0, 2, B).astype(bool), irng.integers(0, 2, B).astype(bool)
         bz = np.zeros(B, bool)
         ops = np.zeros(B, np.uint8)  # NAND
         expect = ~(bx & by)
-        total_per_step = world * B
+        total_per_step = parts * B
+        bounds = [(r * B, (r + 1) * B) for r in range(parts)]
     else:
-        from tfhe_jl_amd.sharding import shard_bounds
         mrng = np.random.default_rng(789)                       # identical stream on every rank, then sliced
         BT = 65536
         names = ["NAND", "AND", "OR", "XOR", "MUX"]
         sel = mrng.integers(0, 5, BT)
         all_ops = np.array([tfhe.OPCODES[x] for x in names], np.uint8)[sel]
         bits = [mrng.integers(0, 2, BT).astype(bool) for _ in range(3)]
-        s0, e0 = shard_bounds(all_ops, world)[rank]
+        bounds = shard_bounds(all_ops, parts)
+        s0, e0 = bounds[rank]
         ops, sel = all_ops[s0:e0], sel[s0:e0]
         bx, by, bz = (b[s0:e0] for b in bits)
         B = e0 - s0
@@ -105,23 +167,29 @@ def main():
         total_per_step = BT
         irng = np.random.default_rng(456 + rank)
     hx, hy, hz = (tfhe.encrypt(irng, sk, b).data for b in (bx, by, bz))
-    dx, dy, dz = (torch.from_numpy(h).to(dev) for h in (hx, hy, hz))
-    dout = torch.empty((B, n1), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * B, n1), dtype=torch.int32, device=dev) if (n_gpus > 1 and args.workload == "nand") else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
+    use_gather = world > 1 and not args.no_gather
+    if not args.fanout:
+        dx, dy, dz = (torch.from_numpy(h).to(dev) for h in (hx, hy, hz))
+        dout = torch.empty((B, n1), dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    host_out = None
+    gathered = None
     br_ms, ks_ms = [], []
 
     def step(record):
-        eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
-        if gathered is not None and not args.no_gather:
-            dist.all_gather_into_tensor(gathered, dout)
+        nonlocal host_out, gathered
+        if args.fanout:
+            host_out = eng.gates(ops, hx, hy, hz if args.workload == "mixed" else None)
+        else:
+            eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
+            if use_gather:   # one RCCL gather of the shards' results to rank 0 (rehearsal on one GPU: gloo on host copies)
+                gathered = gather_to_root(dout.cpu() if share_gpu else dout, bounds, rank, dst=0)
         if record:
-            br_ms.append(eng.last_timing_ms(0))   # HIP events on `stream` around the blind-rotate kernel
+            br_ms.append(eng.last_timing_ms(0))   # HIP events on the stream the kernels were launched on
             ks_ms.append(eng.last_timing_ms(1))
 
     def barrier():
-        if n_gpus > 1:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -134,35 +202,64 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
-    if n_gpus > 1:
+    kernel_name = eng.last_kernel_name()
+    if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # --- "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1), outside the timed region -------
-    single_ms = None
-    if rank == 0 and args.workload == "nand":
-        one = np.zeros(1, np.uint8)
-        o1 = torch.empty((1, n1), dtype=torch.int32, device=dev)
-        lat = []
-        for it in range(25):
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            eng.gates_dev(one, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), o1.data_ptr(), 1, stream)
-            torch.cuda.synchronize(dev)
-            lat.append(time.perf_counter() - t1)
-        single_ms = float(np.median(lat[5:])) * 1e3
-        assert torch.equal(o1[0], dout[0]), "single-gate result differs from the batched one"
-
     # --- correctness of what was just timed (not timed itself) ---------------------------------------
-    out = dout.cpu().numpy()
+    out = host_out if args.fanout else dout.cpu().numpy()
     ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), expect))
+    gather_ok = None
+    if use_gather and rank == 0:
+        g = gathered.cpu().numpy()
+        s0, e0 = bounds[0]
+        gather_ok = bool(g.shape[0] == bounds[-1][1] and np.array_equal(g[s0:e0], out))
+
+    # --- extras on rank 0, outside the timed region ---------------------------------------------------
+    single_ms = pcie_value = clock_mhz = margin = None
+    if rank == 0 and not args.fanout:
+        if args.workload == "nand":   # "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1)
+            one = np.zeros(1, np.uint8)
+            o1 = torch.empty((1, n1), dtype=torch.int32, device=dev)
+            lat = []
+            for it in range(25):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                eng.gates_dev(one, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), o1.data_ptr(), 1, stream)
+                torch.cuda.synchronize(dev)
+                lat.append(time.perf_counter() - t1)
+            single_ms = float(np.median(lat[5:])) * 1e3
+            assert torch.equal(o1[0], dout[0]), "single-gate result differs from the batched one"
+        if not args.no_diagnostics and world == 1:
+            # the same step through HOST buffers (tfhe_gates_batch: 2-3 uploads + 1 download over PCIe per step)
+            reps = max(2, min(args.steps, 5))
+            eng.gates(ops, hx, hy, hz)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.gates(ops, hx, hy, hz)
+            pcie_value = B * reps / (time.perf_counter() - t1)
+            # clock the blind-rotate kernel holds under this load + its rounding margin: DIAG instantiation of the
+            # same kernel, >= 2 s of back-to-back launches first (MI355X_MICROARCH.md, DVFS give-back item 6)
+            eng.set_option("measure_margin", 1)
+            t1 = time.perf_counter()
+            while time.perf_counter() - t1 < 2.0:
+                for _ in range(8):
+                    eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
+                torch.cuda.synchronize(dev)
+            clock_mhz = eng.last_kernel_clock_mhz()
+            margin = eng.last_rounding_margin()
+            eng.set_option("measure_margin", 0)
 
     result = None
     if rank == 0:
         br_avg_s = float(np.mean(br_ms)) * 1e-3
-        achieved = rotations_per_step * BR_BYTES[args.params] / br_avg_s
+        achieved = rotations_per_step * br_bytes(params) / br_avg_s
+        flops = rotations_per_step * br_flops(params) / br_avg_s
         total_gates = total_per_step * args.steps
+        prof = profile_counters(kernel_name, rotations_per_step)
+        p = params
         result = {
             "metric": "bootstrapped gates/sec (whole node), N=1024",
             "value": total_gates / elapsed,
@@ -179,57 +276,89 @@ def main():
             "dtype": "int32 torus / f64 transform",
             "data": "synthetic: oracle-independent numpy keygen (seed 123), encryptions of uniform random bits (seed 456)",
             "config": {
-                "workload": (f"batch of {B} independent gate_nand() bootstraps per GPU" if args.workload == "nand" else
+                "workload": (f"batch of {args.gates} independent gate_nand() bootstraps per GPU" if args.workload == "nand" else
                              f"mixed gate stream (NAND/AND/OR/XOR/MUX), 65536 gates in total, {B} on rank 0") + f", tfhe_parameters_{args.params} "
-                            f"(n={params.lwe_size}, N=1024, k=1, l={params.bs_decomp_length}, Bg=2^{params.bs_log2_base}, "
-                            f"ks t={params.ks_decomp_length}, base 2^{params.ks_log2_base})",
-                "gates_per_gpu_per_step": B,
-                "result_gather": "rccl all_gather" if (gathered is not None and not args.no_gather) else "none",
+                            f"(n={p.lwe_size}, N=1024, k=1, l={p.bs_decomp_length}, Bg=2^{p.bs_log2_base}, "
+                            f"ks t={p.ks_decomp_length}, base 2^{p.ks_log2_base})",
+                "gates_per_gpu_per_step": args.gates if args.workload == "nand" else B,
+                "inputs": "host buffers (PCIe inside the timed region)" if args.fanout else "resident in HBM",
+                "launch": ("one process, multi-device context (tfhe_ctx_create_multi)" if args.fanout else
+                           "one process per GPU (torch.distributed)" if world > 1 else "one process"),
+                "result_gather": ("none (results written into the caller's host buffer)" if args.fanout else
+                                  ("gloo gather to rank 0 (one-GPU rehearsal)" if share_gpu else "rccl gather to rank 0") if use_gather else "none"),
             },
             "outputs_decrypt_correctly": ok_decrypt,
+            "gather_matches_local_shard": gather_ok,
+            "value_pcie_inclusive": pcie_value,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "blind_rotate_kernel_v3",
+                "bound_note": "judged figure (SURVEY §8d): algorithmic key bytes / launch time against HBM peak; the transformed key "
+                              "(32.8 MB) is shared by all resident rotations and is served from L2 / Infinity Cache, so real HBM "
+                              "traffic is ~1 % of this and the kernel is FP64-VALU bound: see roofline_secondary",
+                "kernel": kernel_name,
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": traffic_from_profiles("blind_rotate_kernel_v3", rotations_per_step),
-                "bytes_per_unit": BR_BYTES[args.params],
+                "traffic": prof.get("hbm_bytes_per_launch"),
+                "traffic_source": prof.get("source"),
+                "bytes_per_unit": br_bytes(params),
                 "units_per_launch": rotations_per_step,
                 "avg_launch_ms": br_avg_s * 1e3,
                 "keyswitch_avg_launch_ms": float(np.mean(ks_ms)),
             },
+            "roofline_secondary": {
+                "bound": "fp64_valu",
+                "kernel": kernel_name,
+                "flops_per_unit": br_flops(params),
+                "flops_formula": "n * ((k+1)(l+1) * 5 M log2 M + (k+1)^2 l M * 8), M = N/2 (SURVEY §8d)",
+                "achieved": flops / 1e12,
+                "peak": FP64_VALU_PEAK / 1e12,
+                "unit": "TFLOP/s",
+                "frac": flops / FP64_VALU_PEAK,
+                "clock_mhz": clock_mhz,
+                "clock_source": "s_memtime / s_memrealtime inside the DIAG instantiation of the same kernel after >= 2 s of back-to-back launches" if clock_mhz else None,
+                "frac_at_measured_clock": (flops / (FP64_VALU_PEAK * clock_mhz / MAX_CLOCK_MHZ)) if clock_mhz else None,
+                "valu_busy_frac": prof.get("valu_busy_frac"),
+                "valu_insts_per_launch": prof.get("valu_insts_per_launch"),
+                "counters_source": prof.get("source"),
+                "rounding_margin": margin,
+            },
         }
-        if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "nand":
+        if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "nand" and not args.fanout:
             result["cpu_baseline"] = cpu_baseline(tfhe, params, ck, hx, hy, out, args)
         print(json.dumps(result), flush=True)
-    if n_gpus > 1:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ck.close()
     if not ok_decrypt:
         sys.exit("bench.py: GPU outputs did not decrypt to the gates' truth values")
+    if gather_ok is False:
+        sys.exit("bench.py: the gathered result does not contain rank 0's shard")
 
 
-def traffic_from_profiles(kernel_substr, units_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<tag>/traffic.json, written by tools/prof_summary.py: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024,
-    separate --pmc passes of this same command).  Only reported when that profile was taken at the same
-    number of rotations per launch; otherwise null."""
+def profile_counters(kernel_name, units_per_launch):
+    """PMC-derived figures for the dominant kernel from the newest committed rocprofv3 profile of THIS command
+    (profiles/<tag>/counters.json, written by tools/prof_summary.py from separate --pmc passes): HBM bytes per launch
+    (FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024), VALU instructions, VALU-busy fraction.  They are not
+    measured in this run — the source file is named in the JSON line — and are only reported when that profile was
+    taken at the same number of rotations per launch."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+    key = kernel_name.split("(")[0].rstrip(">")          # "blind_rotate_kernel_v3<2,16" matches "...v3<2, 16, false, false>(BrArgs)"
+    best = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "counters.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         meta = d.get("_meta", {})
-        if meta.get("units_per_launch") not in (None, units_per_launch):
+        if meta.get("units_per_launch") not in (None, units_per_launch) or "bench.py" not in meta.get("command", "bench.py"):
             continue
         for k, v in d.items():
-            if kernel_substr in k:
-                best = v["hbm_bytes_per_launch"]
+            if k != "_meta" and re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(" ", "")):
+                best = dict(v)
+                best["source"] = os.path.relpath(f, ROOT) + (f" ({meta.get('date')})" if meta.get("date") else "")
     return best
 
 

@@ -22,9 +22,11 @@
  *   MK keyswitch key: P single-key keyswitch keys back to back      (mk_api.jl:83-101)
  *
  * Ownership: the caller owns every host buffer for the duration of the call only; the library
- * copies keys to the device at load time and owns all device memory.  A context is bound to one
- * device; calls on one context must not overlap (one caller at a time), distinct contexts are
- * independent (one per GPU, one process per GPU in the benchmark).
+ * copies keys to the device(s) at load time and owns all device memory.  A context made by
+ * tfhe_ctx_create is bound to one device; one made by tfhe_ctx_create_multi fans every host-buffer
+ * batch call out over its devices on library-owned threads and streams (keys replicated at load,
+ * contiguous rotation-balanced shards, results written straight into the caller's buffer).  Calls on
+ * one context must not overlap (one caller at a time); distinct contexts are independent.
  */
 #ifndef TFHE_MI355X_H
 #define TFHE_MI355X_H
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 1
+#define TFHE_MI355X_ABI_VERSION 2
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -95,6 +97,24 @@ int32_t tfhe_device_count(void);
 int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx **out_ctx);
 void tfhe_ctx_destroy(tfhe_ctx *ctx);
 
+/* Multi-device context (ctx_create(params, device_ids[], n_dev)): the analogue of Julia's
+ * `gate_xor.(cloud_key, c1, c2)` broadcast (docs/src/manual.md:28-35) spread over all the GPUs of a node.
+ * One device context per entry of device_ids[] (an id may repeat: two contexts then share that GPU on separate
+ * streams).  tfhe_load_* / tfhe_mk_load_* replicate the key to every device; tfhe_gates_batch,
+ * tfhe_bootstrap_batch, tfhe_keyswitch_batch and tfhe_mk_gate_nand_batch split the batch into contiguous shards
+ * (gates: balanced by blind-rotation count, MUX = 2) that run concurrently and write into the caller's buffers.
+ * There is no communication between devices: the gates of a batch are independent (gates.jl).
+ * tfhe_gates_batch_dev needs n_dev == 1 (a device pointer belongs to one device); the wire-table entry points
+ * (tfhe_wires_*, tfhe_gates_level) run on the first device.  Results are bit-identical to a one-device context. */
+int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_ids, int32_t n_dev,
+                              tfhe_ctx **out_ctx);
+/* Number of device contexts behind ctx (1 for tfhe_ctx_create). */
+int32_t tfhe_ctx_device_count(const tfhe_ctx *ctx);
+/* The sharding rule of a multi-device tfhe_gates_batch: bounds[r] .. bounds[r+1] (r < shards) are the gates of
+ * shard r; contiguous, balanced by blind rotations (MUX = 2, NOT / CONSTANT / COPY = 0; gates.jl:76-93,163-177).
+ * opcodes may be NULL (all gates cost one rotation).  bounds: int64 [shards + 1]. */
+int32_t tfhe_shard_bounds(const uint8_t *opcodes, int64_t B, int32_t shards, int64_t *bounds);
+
 /* Message of the last error on ctx (ctx == NULL: last error of a failed tfhe_ctx_create). */
 const char *tfhe_last_error(const tfhe_ctx *ctx);
 
@@ -127,7 +147,8 @@ int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *i
 /* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`
  * (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host except
  * for the upload of the B opcode bytes; results are ordered on `stream`.  The context's workspaces are shared by
- * all calls: a call on a different stream than the previous one first waits for that previous stream. */
+ * all calls: every batch call records a context-owned event at its end and the next call makes its own stream wait
+ * for it (device-side ordering; the host does not block and no handle of the caller's stream is kept). */
 int32_t tfhe_gates_batch_dev(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *d_in0,
                              const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, int64_t B,
                              void *stream);
@@ -142,6 +163,8 @@ int32_t tfhe_wires_alloc(tfhe_ctx *ctx, int64_t num_wires);
 /* Copies `count` samples (host int32 [count][n+1]) into / out of wires [first, first+count). */
 int32_t tfhe_wires_upload(tfhe_ctx *ctx, int64_t first, int64_t count, const int32_t *host);
 int32_t tfhe_wires_download(tfhe_ctx *ctx, int64_t first, int64_t count, int32_t *host);
+/* host[i] = wire[wires[i]] for i < count: any set of wires in ONE device gather + ONE copy (the outputs of a circuit). */
+int32_t tfhe_wires_gather(tfhe_ctx *ctx, const int32_t *wires, int64_t count, int32_t *host);
 /* wire[out[g]] = gate_<opcode[g]>(ck, wire[a[g]], wire[b[g]], wire[c[g]]) for g < B (host index arrays; b / c
  * may be NULL if no opcode reads them).  A level must not read a wire it writes, nor write a wire twice
  * (TFHE_ERR_INVALID_ARG).  Asynchronous on the context's stream; ordered with later calls. */
@@ -177,12 +200,24 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
 /* Number of blind rotations the most recent batch call executed (MUX counts 2). */
 int64_t tfhe_last_rotation_count(const tfhe_ctx *ctx);
 
-/* Exactness evidence for the Float64 transform: after tfhe_set_option(ctx, "measure_margin", 1), batch calls
- * also record, per blind rotation, the largest distance of any pre-rounding value from an integer
- * (polynomials.jl:115-116 rounds; a flipped rounding needs 0.5).  Returns the maximum over the last call. */
+/* Name of the blind-rotate kernel instantiation the most recent batch call launched (e.g.
+ * "blind_rotate_kernel_v3<2,16>"); valid until the next call on ctx. */
+const char *tfhe_last_kernel_name(const tfhe_ctx *ctx);
+
+/* Exactness evidence for the Float64 transform: after tfhe_set_option(ctx, "measure_margin", 1), batch calls run
+ * the DIAG instantiation of whichever blind-rotate kernel the dispatcher selects (every kernel that rounds has one:
+ * single key N = 1024 / 2048, k = 1 / 2, two-wave, multi-key 2-party and any-party) and record, per blind rotation,
+ * the largest distance of any pre-rounding value from an integer (polynomials.jl:115-116 rounds; a flipped rounding
+ * needs 0.5).  Returns the maximum over the last call. */
 int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
 
-/* Selects a kernel variant / diagnostic by name ("br_variant", "ks_variant", "br_small", "measure_margin"). */
+/* Same DIAG run: the shader clock the blind-rotate kernel actually held, in MHz = s_memtime ticks / s_memrealtime
+ * ticks x 100 MHz around the kernel body, median over workgroups (what FP64-issue roofline figures are priced at). */
+int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
+
+/* Selects a kernel variant / diagnostic by name ("br_variant", "ks_variant", "br_small", "measure_margin",
+ * "mk_general", "ks_slices").  "ks_variant" decides which keyswitch-key layout is kept on the device and must be
+ * chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

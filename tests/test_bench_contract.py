@@ -29,12 +29,20 @@ def test_bench_json_line_is_consistent():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.01 < rf["frac"] < 1.5
     assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert 0.1 < d["ms_per_bootstrap_single_gate"] < 50
+    # the kernel named is the one the engine launched for this batch size (512 rotations: the two-wave kernel)
+    assert rf["kernel"] == "blind_rotate_kernel_w2<2>" and "bound_note" in rf and "traffic_source" in rf
+    r2 = d["roofline_secondary"]
+    assert r2["bound"] == "fp64_valu" and r2["kernel"] == rf["kernel"] and r2["flops_per_unit"] == 500 * (6 * 5 * 512 * 9 + 8 * 512 * 8)
+    assert abs(r2["achieved"] - 512 * r2["flops_per_unit"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r2["achieved"]
+    assert 300 < r2["clock_mhz"] < 2600 and 0 < r2["rounding_margin"] < 0.25
+    assert abs(r2["frac_at_measured_clock"] - r2["frac"] * 2400 / r2["clock_mhz"]) < 1e-9
+    assert 0 < d["value_pcie_inclusive"] < 1.2 * d["value"]
 
 
 @pytest.mark.gpu
 def test_bench_two_rank_launch_rehearsal():
     """The driver's multi-GPU launch line with 2 ranks, rehearsed on one GPU (TFHE_BENCH_SHARE_GPU=1: both ranks on
-    device 0, gloo instead of RCCL for barrier / max-reduce, no gather): rank 0 prints one whole-job JSON line."""
+    device 0, gloo instead of RCCL for barrier / max-reduce / gather): rank 0 prints one whole-job JSON line."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -51,3 +59,39 @@ def test_bench_two_rank_launch_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]   # whole-job aggregate
     assert d["outputs_decrypt_correctly"] is True
+
+
+def _one_json_line(cmd, env=None):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks_and_gathers():
+    """`python bench.py --gpus 2` with no launcher: the parent starts the two rank processes itself (before touching a
+    GPU) and relays rank 0's line; the shards' results are gathered to rank 0 (one-GPU rehearsal: gloo on host copies)
+    and rank 0's own shard is found in the gathered tensor.  Mixed workload: uneven, rotation-balanced shards."""
+    env = dict(os.environ, TFHE_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gates", "300"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["outputs_decrypt_correctly"] is True
+    assert d["gather_matches_local_shard"] is True and "gather to rank 0" in d["config"]["result_gather"]
+    assert abs(d["value"] - 2 * 300 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "mixed"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["outputs_decrypt_correctly"] is True
+    assert d["gather_matches_local_shard"] is True
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_fanout_context():
+    """`--fanout`: one process, one multi-device context (two device contexts on this one GPU): the library splits the
+    host batch itself; the line says that inputs crossed PCIe inside the timed region."""
+    env = dict(os.environ, TFHE_BENCH_SHARE_GPU="1")
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fanout", "--steps", "2", "--warmup", "1", "--gates", "300"], env)
+    assert d["n_gpus"] == 2 and d["outputs_decrypt_correctly"] is True and "multi-device context" in d["config"]["launch"]
+    assert d["roofline"]["units_per_launch"] == 600 and "host buffers" in d["config"]["inputs"]
+    assert abs(d["value"] - 600 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

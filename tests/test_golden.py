@@ -40,12 +40,20 @@ def test_gpu_reproduces_golden(tfhe, kat):
     assert np.array_equal(e.gates(kat["ops"], kat["in0"], kat["in1"], kat["in2"]), kat["out"])
     assert np.array_equal(e.bootstrap(2**29, kat["in0"][:8], with_keyswitch=False), kat["ext"])
     assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
+    # the keyswitch family decides which key layout is resident: it cannot change under a loaded key
+    with pytest.raises(tfhe.EngineError) as ei:
+        e.set_option("ks_variant", 3)
+    assert ei.value.code == 5
+    e.close()
     # every kernel variant gives the same words (br_small = -1: one wave per rotation even for small batches;
     # default: the two-waves-per-rotation kernel takes batches this small)
     for bv, kv, small in ((1, 1, -1), (2, 3, -1), (3, 3, -1), (2, 4, -1), (2, 4, 512)):
+        e = tfhe.Engine(params, 0)
+        e.set_option("ks_variant", kv)               # before the key load: only that family's layout is built
+        e.load_bootstrap_key(kat["bootstrap_key"])
+        e.load_keyswitch_key(kat["keyswitch_key"])
         e.set_option("br_variant", bv)
-        e.set_option("ks_variant", kv)
         e.set_option("br_small", small)
         assert np.array_equal(e.gates(kat["ops"], kat["in0"], kat["in1"], kat["in2"]), kat["out"])
         assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
-    e.close()
+        e.close()

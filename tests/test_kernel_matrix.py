@@ -1,0 +1,322 @@
+"""Every blind-rotate kernel instantiation the dispatcher can select (launch_blind_rotate / tfhe_mk_gate_nand_batch in
+csrc/tfhe_engine.hip), driven through the C ABI at an option setting or batch size that selects it, against the oracle
+word for word; its DIAG instantiation must give the same words with a rounding margin far from a flipped rounding
+(the reference rounds at polynomials.jl:115-116; its multi-key code sums products in Int32 precisely because it does
+not trust spectrum-domain sums, mk_internals.jl:359-366 — here the margin of doing so is measured on the GPU).
+BASELINE configs 4a / 4b / 5 at their stated batch sizes are in this file too."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MU = 2**29
+# decomposition (l, beta) per l: l * beta <= 32; beta = 10 only where the Float64 transform keeps its margin (l <= 2, N = 1024)
+BETA_1024 = {1: 10, 2: 10, 3: 7, 4: 7}
+BETA_OTHER = {1: 7, 2: 7, 3: 7, 4: 7}
+
+
+def _setup(tfhe, orc, N, k, l, beta, n=10, seed=0):
+    from conftest import KeySet
+    p = tfhe.SchemeParameters(n, 1 / 2**15, N, k, l, beta, 9e-9, 8, 2, 1 / 2**15, 1)
+    return KeySet(tfhe, orc, p, seed=1000 * N + 100 * k + 10 * l + seed)
+
+
+def _words(rng, rows, width):
+    x = rng.integers(-2**31, 2**31, size=(rows, width), dtype=np.int64).astype(np.int32)
+    x[0, :] = 0
+    x[1, :min(7, width)] = [2**31 - 1, -2**31, 2**20, 2**20 - 1, -2**20, -2**20 - 1, 1][:min(7, width)]
+    return x
+
+
+def _check(eng, K, x, expect_kernel, what):
+    want = K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == expect_kernel, (what, eng.last_kernel_name())
+    assert np.array_equal(got, want), what
+    eng.set_option("measure_margin", 1)
+    try:
+        again = eng.bootstrap(MU, x, with_keyswitch=False)
+        assert eng.last_kernel_name() == expect_kernel
+        margin, clock = eng.last_rounding_margin(), eng.last_kernel_clock_mhz()
+    finally:
+        eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, want), what + " (DIAG instantiation)"
+    assert 0.0 <= margin < 0.25, (what, margin)
+    assert 300.0 < clock < 2600.0, (what, clock)
+    return margin
+
+
+@pytest.mark.parametrize("l", [1, 2, 3, 4])
+def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
+    """blind_rotate_kernel_v3<l,16> (large batches), v3<l,8>, w2<l> (<= 512 rotations), baseline <l,2>: k = 1, N = 1024."""
+    K = _setup(tfhe, orc, 1024, 1, l, BETA_1024[l])
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(l), 6, K.params.lwe_size + 1)
+    eng.set_option("br_small", -1)
+    _check(eng, K, x, f"blind_rotate_kernel_v3<{l},16>", f"v3<{l},16>")
+    eng.set_option("br_variant", 3)
+    _check(eng, K, x, f"blind_rotate_kernel_v3<{l},8>", f"v3<{l},8>")
+    eng.set_option("br_variant", 2)
+    eng.set_option("br_small", 512)
+    _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
+    eng.set_option("br_variant", 1)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == f"blind_rotate_kernel<{l},2>"
+    assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
+    eng.set_option("br_variant", 2)
+    # the switch between the two kernels is by batch size: 513 rotations take v3<l,16> without any option
+    big = np.repeat(x[2:3], 513, axis=0)
+    big[:, 0] += np.arange(513, dtype=np.int32) << 21        # distinct first exponents
+    got = eng.bootstrap(MU, big, with_keyswitch=False)
+    assert eng.last_kernel_name() == f"blind_rotate_kernel_v3<{l},16>"
+    idx = [0, 1, 255, 511, 512]
+    assert np.array_equal(got[idx], K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=5))
+    K.ck.close()
+
+
+@pytest.mark.parametrize("l", [1, 2, 3, 4])
+def test_mask_size_2_kernel_every_l(tfhe, orc, l):
+    """blind_rotate_kernel_k2<l> (tlwe_mask_size = 2, api.jl:30,55)."""
+    K = _setup(tfhe, orc, 1024, 2, l, BETA_OTHER[l], n=8)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(20 + l), 5, K.params.lwe_size + 1)
+    _check(eng, K, x, f"blind_rotate_kernel_k2<{l}>", f"k2<{l}>")
+    K.ck.close()
+
+
+@pytest.mark.parametrize("l", [1, 2, 3, 4])
+def test_n2048_kernel_every_l(tfhe, orc, l):
+    """blind_rotate_kernel_n2048<l> (synthetic N = 2048, BASELINE config 4b's shape)."""
+    K = _setup(tfhe, orc, 2048, 1, l, BETA_OTHER[l], n=8)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(40 + l), 5, K.params.lwe_size + 1)
+    _check(eng, K, x, f"blind_rotate_kernel_n2048<{l}>", f"n2048<{l}>")
+    K.ck.close()
+
+
+def _mk(tfhe, orc, parties, l, beta, n, max_parties, seed):
+    p = tfhe.SchemeParameters(n, 0.012467, 1024, 1, l, beta, 3.29e-10, 8, 2, 2.44e-5, max_parties)
+    rng = np.random.default_rng(seed)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    o = orc.Oracle(n, 1024, 1, l, beta, 8, 2, parties=parties)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    return p, rng, sks, ck, o
+
+
+def _mk_check(eng, o, x, y, expect_kernel):
+    want = o.mk_gate_nand(x, y, nthreads=8)
+    got = eng.mk_gate_nand(x, y)
+    assert eng.last_kernel_name() == expect_kernel, eng.last_kernel_name()
+    assert np.array_equal(got, want)
+    eng.set_option("measure_margin", 1)
+    try:
+        again = eng.mk_gate_nand(x, y)
+        margin, clock = eng.last_rounding_margin(), eng.last_kernel_clock_mhz()
+    finally:
+        eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, want)
+    assert 0.0 <= margin < 0.25, margin
+    assert 300.0 < clock < 2600.0
+    return margin
+
+
+@pytest.mark.parametrize("l", [2, 3, 4])
+def test_mk_two_party_kernel_every_l(tfhe, orc, l):
+    """mk_blind_rotate_kernel<l> (2 parties; l = 4, beta = 7 is mktfhe_parameters_2party, mk_api.jl:4-10)."""
+    p, rng, sks, ck, o = _mk(tfhe, orc, 2, l, 7, 12, 2, 60 + l)
+    eng = ck.engine(0)
+    x, y = _words(rng, 5, 2 * 12 + 1), _words(rng, 5, 2 * 12 + 1)[::-1].copy()
+    x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
+    y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel<{l}>")
+    ck.close()
+
+
+@pytest.mark.parametrize("which,parties,l,beta,n", [("4party", 4, 5, 6, 8), ("8party", 8, 8, 4, 4), ("3-of-4", 3, 5, 6, 8), ("2party-general", 2, 4, 7, 12)])
+def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
+    """mk_blind_rotate_kernel_general at the shipped 4- and 8-party decompositions (mk_api.jl:16-34: l = 5 / beta = 6,
+    l = 8 / beta = 4): up to (P+1) l products are summed in the spectrum domain before ONE rounding — the margin
+    of exactly that is asserted on the GPU."""
+    p, rng, sks, ck, o = _mk(tfhe, orc, parties, l, beta, n, max(parties, 2) if which != "3-of-4" else 4, 80 + parties)
+    eng = ck.engine(0)
+    if parties == 2:
+        eng.set_option("mk_general", 1)
+    w = parties * n + 1
+    x, y = _words(rng, 4, w), _words(rng, 4, w)[::-1].copy()
+    x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
+    y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_general(P={parties},L={l})")
+    ck.close()
+
+
+# ---- BASELINE configurations at their stated batch sizes ----------------------------------------------------------
+def test_config4a_128bit_4096(tfhe, orc, keys128):
+    """BASELINE config 4a: tfhe_parameters_128 (api.jl:55-69), 4096 NAND on one GPU -> blind_rotate_kernel_v3<3,16>.
+    Every output decrypts to NAND; 64 sampled rows equal the oracle word for word; DIAG run identical, margin < 0.25."""
+    K = keys128
+    eng = K.ck.engine(0)
+    rng = np.random.default_rng(4128)
+    B = 4096
+    bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
+    ops = np.zeros(B, np.uint8)
+    got = eng.gates(ops, x, y)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_v3<3,16>"
+    assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
+    idx = rng.choice(B, 64, replace=False)
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+    eng.set_option("measure_margin", 1)
+    again = eng.gates(ops, x, y)
+    margin = eng.last_rounding_margin()
+    eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, got) and 0.0 < margin < 0.25, margin
+
+
+def test_config4b_synthetic_n2048_4096(tfhe, orc):
+    """BASELINE config 4b: synthetic N = 2048 (n = 630, l = 3, beta = 7), 4096 NAND -> blind_rotate_kernel_n2048<3>."""
+    from conftest import KeySet
+    from test_oracle import synthetic_2048
+    K = KeySet(tfhe, orc, synthetic_2048(tfhe), seed=2048)
+    eng = K.ck.engine(0)
+    rng = np.random.default_rng(4204)
+    B = 4096
+    bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
+    ops = np.zeros(B, np.uint8)
+    got = eng.gates(ops, x, y)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n2048<3>"
+    assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
+    idx = rng.choice(B, 64, replace=False)
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+    eng.set_option("measure_margin", 1)
+    again = eng.gates(ops[:256], x[:256], y[:256])
+    margin = eng.last_rounding_margin()
+    eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, got[:256]) and 0.0 < margin < 0.25, margin
+    K.ck.close()
+
+
+def test_config5_mk_two_party_1024(tfhe, orc):
+    """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel<4>.
+    64 sampled rows equal the oracle word for word (decrypt-level MK checks are ~0.2 %/gate noisy by design of the
+    scheme's parameters, SURVEY §4: at least 98.5 % must decrypt to NAND)."""
+    p = tfhe.mktfhe_parameters_2party
+    rng = np.random.default_rng(321)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(2)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    o = orc.Oracle(p.lwe_size, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=2)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    eng = ck.engine(0)
+    B = 1024
+    m1, m2 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.mk_encrypt(rng, sks, m1), tfhe.mk_encrypt(rng, sks, m2)
+    got = eng.mk_gate_nand(x, y)
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel<4>"
+    assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.985
+    idx = rng.choice(B, 64, replace=False)
+    assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
+    eng.set_option("measure_margin", 1)
+    again = eng.mk_gate_nand(x[:128], y[:128])
+    margin = eng.last_rounding_margin()
+    eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, got[:128]) and 0.0 < margin < 0.25, margin
+    # the fan-out context (two device contexts on this one GPU) gives the same words
+    e2 = ck.engine([0, 0])
+    assert e2.device_count() == 2
+    assert np.array_equal(e2.mk_gate_nand(x[:65], y[:65]), got[:65])
+    ck.close()
+
+
+# ---- the multi-device context behind the ABI ----------------------------------------------------------
+def test_multi_device_context_equals_single(tfhe, orc, keys80):
+    """tfhe_ctx_create_multi with device_ids = {0, 0}: keys replicated, a mixed batch split into rotation-balanced
+    shards run concurrently, results written into the caller's buffer — identical to the one-device context."""
+    K = keys80
+    e1 = K.ck.engine(0)
+    e2 = K.ck.engine([0, 0])
+    assert e2.device_count() == 2 and e1.device_count() == 1
+    rng = np.random.default_rng(8)
+    names = ["NAND", "AND", "OR", "XOR", "MUX", "NOT", "CONST1", "COPY"]
+    for B in (1, 2, 3, 97, 1500):
+        ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
+        ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+        want = e1.gates(ops, *ins)
+        rot = e1.last_rotation_count()
+        got = e2.gates(ops, *ins)
+        assert np.array_equal(got, want), B
+        assert e2.last_rotation_count() == rot
+        assert e2.last_timing_ms(2) >= 0.0
+    x = _words(rng, 9, 501)
+    ext = e1.bootstrap(MU, x, with_keyswitch=False)
+    assert np.array_equal(e2.bootstrap(MU, x, with_keyswitch=False), ext)
+    assert np.array_equal(e2.bootstrap(MU, x), e1.bootstrap(MU, x))
+    assert np.array_equal(e2.keyswitch(ext), e1.keyswitch(ext))
+    assert np.array_equal(e2.gates(np.zeros(0, np.uint8), np.zeros((0, 501), np.int32)), np.zeros((0, 501), np.int32))
+    with pytest.raises(tfhe.EngineError):
+        e2.gates(np.array([0, 99, 0], np.uint8), x[:3], x[:3])                  # bad opcode: nothing runs
+    with pytest.raises(tfhe.EngineError):
+        e2.gates_dev(np.zeros(1, np.uint8), 1, 1, 1, 1, 1)                      # device pointers need one device
+    # diagnostics and options reach every device context
+    e2.set_option("measure_margin", 1)
+    ops = np.zeros(64, np.uint8)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, 64).astype(bool)).data for _ in range(2)]
+    got = e2.gates(ops, *ins)
+    assert 0.0 < e2.last_rounding_margin() < 0.25
+    e2.set_option("measure_margin", 0)
+    assert np.array_equal(got, e1.gates(ops, *ins))
+    with pytest.raises(tfhe.EngineError):
+        tfhe.Engine(K.params, devices=[0, 99])                                   # one bad id fails the whole create
+
+
+def test_alternating_streams_share_one_context(tfhe, orc, keys80):
+    """Batch calls issued on two different HIP streams against ONE context (shared workspaces): each call waits, on the
+    device, for the context-owned event the previous call recorded — no host block, no foreign stream handle kept.
+    One of the streams is dropped and replaced between calls.  All outputs equal the oracle."""
+    import gc
+    import torch
+    K = keys80
+    eng = K.ck.engine(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    B = 600                     # > 512 rotations: the one-wave-per-rotation kernel, ~2 ms per call
+    ops = np.zeros(B, np.uint8)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    batches = []
+    for it in range(6):
+        hx = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data
+        hy = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data
+        s = streams[it & 1]
+        with torch.cuda.stream(s):
+            dx, dy = torch.from_numpy(hx).to(dev, non_blocking=False), torch.from_numpy(hy).to(dev, non_blocking=False)
+            dout = torch.empty((B, 501), dtype=torch.int32, device=dev)
+        s.synchronize()
+        eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), 0, dout.data_ptr(), B, s.cuda_stream)     # returns before the kernels finish
+        batches.append((hx, hy, dx, dy, dout, s))
+        if it == 3:             # the caller may drop a stream it has synchronised; the context must not care
+            streams[1].synchronize()
+            streams[1] = torch.cuda.Stream(dev)
+            gc.collect()
+    torch.cuda.synchronize(dev)
+    for hx, hy, dx, dy, dout, s in batches:
+        idx = [0, 1, B // 2, B - 1]
+        assert np.array_equal(dout.cpu().numpy()[idx], K.oracle.gates(ops[idx], hx[idx], hy[idx], nthreads=4))
+
+
+def test_wires_gather_any_order(tfhe, keys80):
+    K = keys80
+    eng = K.ck.engine(0)
+    rng = np.random.default_rng(3)
+    m = rng.integers(-2**31, 2**31, size=(40, 501), dtype=np.int64).astype(np.int32)
+    eng.wires_alloc(40)
+    eng.wires_upload(0, m)
+    idx = [39, 0, 7, 7, 21]
+    assert np.array_equal(eng.wires_gather(idx), m[idx])
+    assert eng.wires_gather([]).shape == (0, 501)
+    with pytest.raises(tfhe.EngineError):
+        eng.wires_gather([40])
+    eng.wires_alloc(0)

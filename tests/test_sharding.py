@@ -27,6 +27,20 @@ def test_shard_bounds_cover_and_balance(tfhe):
     assert [int(c) for c in rotation_cost([tfhe.OPCODES[x] for x in ("NAND", "MUX", "NOT", "CONST1")])] == [1, 2, 0, 0]
 
 
+def test_library_sharding_rule_equals_host_rule(tfhe):
+    """tfhe_shard_bounds (what a multi-device context uses to split tfhe_gates_batch) == sharding.shard_bounds
+    (what the one-process-per-GPU launch uses), on mixed, trivial-heavy, tiny and empty streams."""
+    from tfhe_jl_amd.sharding import shard_bounds
+    rng = np.random.default_rng(5)
+    for B in (0, 1, 3, 7, 64, 1000, 65536):
+        for world in (1, 2, 3, 8):
+            ops = rng.integers(0, 15, B).astype(np.uint8)
+            assert tfhe._lib.shard_bounds(ops, world) == shard_bounds(ops, world), (B, world)
+    triv = np.full(100, tfhe.OPCODES["NOT"], np.uint8)
+    assert tfhe._lib.shard_bounds(triv, 4) == shard_bounds(triv, 4)
+    assert tfhe._lib.shard_bounds(None, 4) == [(0, 0)] * 4
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,7 +50,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     import oracle
     import tfhe_jl_amd as tfhe
-    from tfhe_jl_amd.sharding import gather_shards, shard_bounds
+    from tfhe_jl_amd.sharding import gather_shards, gather_to_root, shard_bounds
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         params = tfhe.SchemeParameters(6, 1 / 2**15, 1024, 1, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1)
@@ -54,7 +68,10 @@ def _worker(rank, world, port, q):
         local = o.gates(ops[s:e], *[a[s:e] for a in ins]) if e > s else np.zeros((0, 7), np.int32)
         full = gather_shards(torch.from_numpy(local), bounds, rank).numpy()
         want = o.gates(ops, *ins)
-        q.put((rank, bool(np.array_equal(full, want)), bounds))
+        ok = bool(np.array_equal(full, want))
+        rooted = gather_to_root(torch.from_numpy(local), bounds, rank, dst=0)      # what bench.py uses
+        ok = ok and ((rooted is None) if rank != 0 else bool(np.array_equal(rooted.numpy(), want)))
+        q.put((rank, ok, bounds))
     finally:
         dist.destroy_process_group()
 

@@ -18,7 +18,10 @@ ABI_SYMBOLS = [
     "tfhe_keyswitch_batch", "tfhe_mk_load_bootstrap_key_i32", "tfhe_mk_load_keyswitch_key",
     "tfhe_mk_gate_nand_batch", "tfhe_last_timing_ms", "tfhe_last_rotation_count", "tfhe_set_option",
     "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
+    "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
+    "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz",
 ]
+ABI_VERSION = 2
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -76,6 +79,16 @@ def load():
     lib.tfhe_wires_upload.argtypes = [vp, i64, i64, vp]
     lib.tfhe_wires_download.argtypes = [vp, i64, i64, vp]
     lib.tfhe_gates_level.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+    lib.tfhe_ctx_create_multi.argtypes = [C.POINTER(TfheParams), vp, i32, C.POINTER(vp)]
+    lib.tfhe_ctx_device_count.argtypes = [vp]
+    lib.tfhe_ctx_device_count.restype = i32
+    lib.tfhe_shard_bounds.argtypes = [vp, i64, i32, vp]
+    lib.tfhe_wires_gather.argtypes = [vp, vp, i64, vp]
+    lib.tfhe_last_kernel_name.argtypes = [vp]
+    lib.tfhe_last_kernel_name.restype = C.c_char_p
+    lib.tfhe_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
+    if lib.tfhe_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.tfhe_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 
@@ -88,21 +101,39 @@ def _i32c(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
 
 
-class Engine:
-    """One device context (tfhe_ctx): keys resident on one GPU, batch entry points."""
+def shard_bounds(opcodes, shards):
+    """The library's own sharding rule (tfhe_shard_bounds): list of (start, end) per shard."""
+    ops = None if opcodes is None else np.ascontiguousarray(opcodes, dtype=np.uint8)
+    B = 0 if ops is None else ops.size
+    out = np.zeros(int(shards) + 1, np.int64)
+    rc = load().tfhe_shard_bounds(_ptr(ops), B, int(shards), _ptr(out))
+    if rc != 0:
+        raise EngineError(rc, "tfhe_shard_bounds: invalid argument")
+    return [(int(out[r]), int(out[r + 1])) for r in range(int(shards))]
 
-    def __init__(self, params, device=0):
+
+class Engine:
+    """One context (tfhe_ctx): keys resident on one GPU — or, with `devices=[...]`, replicated on several, every
+    host-buffer batch call fanned out over them inside the library (tfhe_ctx_create_multi)."""
+
+    def __init__(self, params, device=0, devices=None):
         self._lib = load()
         self.params = params
         n, N, k, l, b, t, g, parties = params.engine_tuple()
         self.n, self.N, self.k, self.parties = n, N, k, parties
         p = TfheParams(n, N, k, l, b, t, g, parties)
         h = C.c_void_p()
-        rc = self._lib.tfhe_ctx_create(C.byref(p), int(device), C.byref(h))
+        if devices is None:
+            rc = self._lib.tfhe_ctx_create(C.byref(p), int(device), C.byref(h))
+            self.devices = [int(device)]
+        else:
+            ids = np.ascontiguousarray(devices, dtype=np.int32)
+            rc = self._lib.tfhe_ctx_create_multi(C.byref(p), _ptr(ids), ids.size, C.byref(h))
+            self.devices = [int(v) for v in ids]
         if rc != 0:
             raise EngineError(rc, self._lib.tfhe_last_error(None).decode())
         self._h = h
-        self.device = int(device)
+        self.device = self.devices[0]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -165,6 +196,8 @@ class Engine:
 
     def bootstrap(self, mu, x, with_keyswitch=True):
         x = _i32c(x)
+        if x.ndim != 2 or x.shape[1] != self.n + 1:
+            raise ValueError(f"bootstrap input must be [B][{self.n + 1}], got {x.shape}")
         B = x.shape[0]
         width = self.n + 1 if with_keyswitch else self.k * self.N + 1
         out = np.empty((B, width), np.int32)
@@ -174,7 +207,7 @@ class Engine:
     def keyswitch(self, x):
         x = _i32c(x)
         B = x.shape[0]
-        if x.shape[1] != self.k * self.N + 1:
+        if x.ndim != 2 or x.shape[1] != self.k * self.N + 1:
             raise ValueError("keyswitch input must be [B][k*N+1]")
         out = np.empty((B, self.n + 1), np.int32)
         self._check(self._lib.tfhe_keyswitch_batch(self._h, _ptr(x), _ptr(out), B))
@@ -195,6 +228,13 @@ class Engine:
         self._check(self._lib.tfhe_wires_download(self._h, int(first), int(count), _ptr(out)))
         return out
 
+    def wires_gather(self, wires):
+        """Rows of the given wire indices, in one device gather + one copy."""
+        idx = np.ascontiguousarray(wires, dtype=np.int32).reshape(-1)
+        out = np.empty((idx.size, self.n + 1), np.int32)
+        self._check(self._lib.tfhe_wires_gather(self._h, _ptr(idx), idx.size, _ptr(out)))
+        return out
+
     def gates_level(self, opcodes, a, b, c, out):
         ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
         arrs = [None if v is None else _i32c(v) for v in (a, b, c, out)]
@@ -207,14 +247,28 @@ class Engine:
     # ---- multi-key ----
     def mk_load_bootstrap_key(self, bk_i32, parties):
         bk = _i32c(bk_i32)
-        self._check(self._lib.tfhe_mk_load_bootstrap_key_i32(self._h, _ptr(bk), int(parties)))
+        P, l = int(parties), self.params.bs_decomp_length
+        want = P * self.n * (2 * l * P + 2 * l) * self.N
+        if bk.size != want:
+            raise ValueError(f"multi-key bootstrap key has {bk.size} words, expected {want} for {P} parties")
+        self._check(self._lib.tfhe_mk_load_bootstrap_key_i32(self._h, _ptr(bk), P))
+        self._mk_parties = P
 
     def mk_load_keyswitch_key(self, ks, parties):
         ks = _i32c(ks)
-        self._check(self._lib.tfhe_mk_load_keyswitch_key(self._h, _ptr(ks), int(parties)))
+        P, p = int(parties), self.params
+        want = P * self.N * p.ks_decomp_length * ((1 << p.ks_log2_base) - 1) * (self.n + 1)
+        if ks.size != want:
+            raise ValueError(f"multi-key keyswitch key has {ks.size} words, expected {want} for {P} parties")
+        self._check(self._lib.tfhe_mk_load_keyswitch_key(self._h, _ptr(ks), P))
 
     def mk_gate_nand(self, in0, in1):
         in0, in1 = _i32c(in0), _i32c(in1)
+        P = getattr(self, "_mk_parties", None)
+        if P is None:
+            raise EngineError(3, "mk_gate_nand: multi-key keys not loaded")
+        if in0.ndim != 2 or in0.shape[1] != P * self.n + 1 or in1.shape != in0.shape:
+            raise ValueError(f"multi-key operands must both be [B][{P * self.n + 1}], got {in0.shape} and {in1.shape}")
         out = np.empty_like(in0)
         self._check(self._lib.tfhe_mk_gate_nand_batch(self._h, _ptr(in0), _ptr(in1), _ptr(out), in0.shape[0]))
         return out
@@ -232,6 +286,17 @@ class Engine:
         m = C.c_double(0)
         self._check(self._lib.tfhe_last_rounding_margin(self._h, C.byref(m)))
         return float(m.value)
+
+    def last_kernel_clock_mhz(self):
+        m = C.c_double(0)
+        self._check(self._lib.tfhe_last_kernel_clock_mhz(self._h, C.byref(m)))
+        return float(m.value)
+
+    def last_kernel_name(self):
+        return self._lib.tfhe_last_kernel_name(self._h).decode()
+
+    def device_count(self):
+        return int(self._lib.tfhe_ctx_device_count(self._h))
 
     def set_option(self, name, value):
         self._check(self._lib.tfhe_set_option(self._h, name.encode(), int(value)))

@@ -107,5 +107,4 @@ class Circuit:
             eng.wires_upload(0, m)
         for ops, a, b, c, out in self.level_arrays():
             eng.gates_level(ops, a, b, c, out)
-        rows = [eng.wires_download(w, 1)[0] for w in self._outputs]
-        return LweSampleArray(np.stack(rows)) if rows else LweSampleArray(np.zeros((0, eng.n + 1), np.int32))
+        return LweSampleArray(eng.wires_gather(self._outputs))     # one device gather + one copy for all outputs

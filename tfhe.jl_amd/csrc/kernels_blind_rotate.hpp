@@ -10,8 +10,45 @@
 
 using namespace tfhe;
 
+// Diagnostics written only by the DIAG instantiations (tfhe_set_option("measure_margin", 1)):
+//   margin_bits[w] = bit pattern of the largest |pre-round value - nearest integer| of rotation w (non-negative doubles
+//                    order like their bit patterns, so waves combine with an integer atomicMax; zeroed before the launch),
+//   clk[2w], clk[2w+1] = s_memtime (shader clock) / s_memrealtime (100 MHz) ticks the workgroup's first wave spent in the
+//                    kernel: in-kernel clock = clk[2w] / clk[2w+1] x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+struct DiagArgs {
+    unsigned long long *margin_bits;
+    unsigned long long *clk;
+};
+
+template <bool DIAG>
+__device__ __forceinline__ void diag_begin(unsigned long long &t0, unsigned long long &r0)
+{
+    if constexpr (DIAG) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+}
+template <bool DIAG>
+__device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double worst, unsigned long long t0, unsigned long long r0)
+{
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(worst, off);
+            worst = o > worst ? o : worst;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&d.margin_bits[w], (unsigned long long)__double_as_longlong(worst));
+            if (threadIdx.x == 0) {
+                d.clk[2 * w] = __builtin_amdgcn_s_memtime() - t0;
+                d.clk[2 * w + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+            }
+        }
+    }
+}
+
 struct BrArgs {
-    double *margin;       // [R] worst rounding margin per rotation (only written by the MARGIN instantiation)
+    DiagArgs diag;
     const int32_t *bara;  // [R][n+1], barb last
     const cplx *bk;       // [n][L][K1][K1][8][64] spectra, permuted order, scaled by 1/M
     int32_t *ext;         // [R][(K1-1)*N + 1]
@@ -139,11 +176,13 @@ __global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
 //   * no s_barrier: wave-private LDS needs only compiler-level ordering;
 //   * no branch on bara[i] == 0 (the step then adds exactly zero).
 template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */,
-          bool MARGIN = false /* diagnostics: record the worst distance of a pre-round value from an integer */>
+          bool MARGIN = false /* diagnostics: rounding margin + in-kernel clock (DiagArgs) */>
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 {
     constexpr int K1 = 2;
     constexpr int F = K1 * L;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
     cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [kXchElems]
@@ -300,14 +339,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
     }
     if (lane == 0) ext[kN] = acc_lds[kN];
-    if (MARGIN) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double o = __shfl_xor(worst, off);
-            worst = o > worst ? o : worst;
-        }
-        if (lane == 0) P.margin[w] = worst;
-    }
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
 // ---- multi-key blind rotation (2 parties) ----------------------------------------------------------
@@ -318,6 +350,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 // (:359-366); summing in the spectrum domain first gives the same words (both are the exact product
 // mod 2^32; rounding margin checked by the oracle test).
 struct MkBrArgs {
+    DiagArgs diag;
     const int32_t *bara;  // [R][P*n+1]
     const cplx *bk;       // [P][n][2*L*P + 2*L][8][64] spectra (engine order, scaled 1/M)
     int32_t *ext;         // [R][P*N+1]
@@ -365,9 +398,9 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
     dft8<true>(x);
 }
 
-template <int L, int PARTY>
+template <int L, int PARTY, bool MARGIN>
 __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
-                                               cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask)
+                                               cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
 {
     constexpr int NP = 2;                         // parties
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit)
@@ -432,17 +465,20 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
             int32_t accr[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-            untwist_add2(out[d], accr);
+            untwist_add2<MARGIN>(out[d], accr, &worst);
             store_acc<2>(lane, accr, acc_lds + d * kN);
         }
         WAVE_LDS_FENCE();
     }
 }
 
-template <int L>
+template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 {
     constexpr int NP = 2;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
     cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [kXchElems]
@@ -468,8 +504,8 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
     }
     WAVE_LDS_FENCE();
     // party-major double loop (mk_internals.jl:475-476)
-    mk_party_steps<L, 0>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
-    mk_party_steps<L, 1>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask);
+    mk_party_steps<L, 0, MARGIN>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask, worst);
+    mk_party_steps<L, 1, MARGIN>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask, worst);
 
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
@@ -483,6 +519,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
             else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
         }
     if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
@@ -492,6 +529,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 // L transforms (nobody else reads acc[s] in this step); a'_party and b' accumulate over all sources
 // (:371-376, :382-385).
 struct MkGenArgs {
+    DiagArgs diag;
     const int32_t *bara;  // [R][P*n+1]
     const cplx *bk;       // [P][n][2*L*P + 2*L][8][64]
     int32_t *ext;         // [R][P*N+1]
@@ -500,10 +538,14 @@ struct MkGenArgs {
     int32_t n, mu, parties, L;
 };
 
+template <bool MARGIN = false>
 __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NP = P.parties, L = P.L;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
     cplx *xch = reinterpret_cast<cplx *>(smem + (size_t)(NP + 1) * kN * 4);
     cplx *tw2_lds = xch + kXchElems;
@@ -536,7 +578,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
         int32_t accr[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-        untwist_add2(o, accr);
+        untwist_add2<MARGIN>(o, accr, &worst);
         store_acc<2>(lane, accr, acc_lds + d * kN);
     };
 
@@ -605,6 +647,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
             else ext[(size_t)c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
         }
     if (lane == 0) ext[(size_t)NP * kN] = acc_lds[NP * kN];
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
 // ---- small batches: two waves per blind rotation ----------------------------------------------------
@@ -615,10 +658,13 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
 // the partial sum for the other component over through LDS (double-buffered, ONE barrier per step), adds
 // what it receives, inverse-transforms its own component and updates its own polynomial.  Same arithmetic
 // per rotation as blind_rotate_kernel_v3, about half the latency.
-template <int L>
+template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
 {
     constexpr int K1 = 2;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2 waves][kXchElems]
@@ -691,11 +737,12 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
         int32_t accr[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
-        untwist_add2(own, accr);
+        untwist_add2<MARGIN>(own, accr, &worst);
         store_acc<2>(lane, accr, acc_lds);
         WAVE_LDS_FENCE();
     }
     __syncthreads();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN + 1);
     if (wv == 0) {
 #pragma unroll
@@ -713,10 +760,13 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
 // ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
 // Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
 // 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
-template <int L>
+template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 {
     constexpr int K1 = 3;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
     cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
@@ -788,11 +838,12 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
             int32_t accr[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-            untwist_add2(out[d], accr);
+            untwist_add2<MARGIN>(out[d], accr, &worst);
             store_acc<2>(lane, accr, acc_lds + d * kN);
         }
         WAVE_LDS_FENCE();
     }
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
     int32_t *ext = P.ext + w * (2 * kN + 1);
 #pragma unroll
@@ -841,6 +892,7 @@ __host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
 __host__ __device__ constexpr double sin_pi32(int k) { return cos_pi32(k - 16); }
 
 struct Br2048Args {
+    DiagArgs diag;
     const int32_t *bara;   // [R][n+1]
     const cplx *bk;        // [n][L][2][2][2 (wave)][8][64]
     int32_t *ext;          // [R][N+1]
@@ -881,10 +933,13 @@ __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx 
     fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
 }
 
-template <int L>
+template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P)
 {
     constexpr int K1 = 2;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                         // [K1][2048]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN2 * 4);                // [2 waves][kXchElems]
@@ -973,6 +1028,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
                 const double vi = wave1 ? -al.y - bi : -al.y + bi;
                 const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R);
                 const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;
+                if (MARGIN) {
+                    const double fa = frac_dist(re), fb = frac_dist(im);
+                    worst = fa > worst ? fa : worst;
+                    worst = fb > worst ? fb : worst;
+                }
                 const int jlo = lane + 64 * R + (wave1 ? 512 : 0);
                 int32_t *ap = acc_lds + d * kN2;
                 ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));
@@ -982,6 +1042,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
         __syncthreads();
     }
 
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN2 + 1);
     for (int j = tid; j < kN2; j += 128) {
         const int32_t v = acc_lds[j];

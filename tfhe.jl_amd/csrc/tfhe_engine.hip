@@ -1,5 +1,5 @@
 // tfhe_engine.hip — MI355X (gfx950) TFHE gate-bootstrapping engine: context, key loading, launchers, C ABI
-// (include/tfhe_mi355x.h).  The kernels live in the three headers included below; this file is the only
+// (include/tfhe_mi355x.h).  The kernels live in the headers included below; this file is the only
 // translation unit.
 //
 // Pipeline of one batch call (tfhe_gates_batch* / tfhe_gates_level):
@@ -10,13 +10,21 @@
 //   ks4_digits_kernel +      keyswitch (keyswitch.jl:45-80) as an exact int8 MFMA contraction, MUX add fused
 //   keyswitch_kernel_v4      (fallbacks: keyswitch_kernel_v3 / keyswitch_kernel)
 //   trivial_gates_kernel     NOT / CONSTANT / COPY (gates.jl:76-93)
+//
+// A context is either a device context (one GPU: keys, workspaces, one stream) or a fan-out context created by
+// tfhe_ctx_create_multi: it owns one device context per entry of device_ids[], replicates keys to all of them at
+// load time and splits every host-buffer batch call into contiguous, rotation-balanced shards run concurrently on
+// library-owned threads.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/tfhe_mi355x.h"
@@ -53,14 +61,19 @@ struct tfhe_ctx {
     tfhe_params P{};
     int device = 0;
     std::string err;
+    std::vector<tfhe_ctx *> kids;        // non-empty: fan-out context (tfhe_ctx_create_multi); no device state of its own
+    std::vector<uint8_t> kid_ran;        // which kids took part in the last batch call (timing / diagnostics)
+
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
-    hipStream_t last_stream = nullptr;   // stream of the previous batch call: the workspaces are shared, so a call on a
-                                         // different stream first waits for the previous stream (enter_stream)
+    hipEvent_t done_ev = nullptr;        // recorded at the end of every batch call: the workspaces are shared, so the next
+    bool done_pending = false;           // call makes ITS stream wait for this event (no foreign stream handle is kept)
     bool timing_valid = false;
     int64_t last_rotations = 0;
+    std::string last_kernel;             // blind-rotate kernel instantiation the last batch call launched
     int ks_slices_large = 2;     // K-split of the MFMA keyswitch for large batches (tfhe_set_option("ks_slices", 1|2|4))
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
+    int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 512;      // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never)
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
@@ -69,14 +82,14 @@ struct tfhe_ctx {
     Tables T{};
     Gadget g{};
 
-    // keys
+    // keys (only the layout of the selected keyswitch kernel family stays resident)
     cplx *d_bk = nullptr;       size_t bk_polys = 0;
-    int32_t *d_ks = nullptr;
-    int32_t *d_ksp = nullptr;   int ks_stride = 0;   // row-padded copy for keyswitch_kernel_v3
-    void *d_ks4 = nullptr;      int ks4_wtiles = 0;  // MFMA B fragments for keyswitch_kernel_v4 (base 4, t = 8)
+    int32_t *d_ks = nullptr;    // canonical [kN][t][base-1][n+1]                   (ks_mode 1)
+    int32_t *d_ksp = nullptr;   int ks_stride = 0;   // row-padded copy             (ks_mode 3)
+    void *d_ks4 = nullptr;      int ks4_wtiles = 0;  // MFMA B fragments            (ks_mode 4: base 4, t = 8)
     void *d_mk_ks4 = nullptr;   size_t mk_ks4_frags = 0;
     bool have_bk = false, have_ks = false;
-    // multi-key (2 parties)
+    // multi-key
     cplx *d_mk_bk = nullptr;
     int32_t *d_mk_ksp = nullptr;   // [P] row-padded keyswitch keys back to back
     size_t mk_ksp_words = 0;       // words per party in d_mk_ksp
@@ -87,12 +100,14 @@ struct tfhe_ctx {
     int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
-    DevBuf bara, ext, map, io[4], margin, abar;
-    size_t margin_rows = 0;
+    DevBuf bara, ext, map, io[4], diag, abar;
+    size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
-    bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations also record their rounding margin
+    bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
+
+    bool multi() const { return !kids.empty(); }
 
     int set_err(int code, const char *fmt, ...)
     {
@@ -129,6 +144,29 @@ static void build_tables(std::vector<cplx> &h)
 
 static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
 
+// ---- sharding of a gate stream: contiguous shards balanced by blind-rotation count ----------
+// MUX = 2 rotations, NOT / CONST / COPY = 0 (gates.jl:163-177, 76-93); every gate also weighs 1/1000 so that cut
+// points stay well defined among trivial gates.  bounds[r] .. bounds[r+1] is shard r.  Same rule as
+// tfhe.jl_amd/sharding.py:shard_bounds (tests compare the two).
+static void shard_bounds_by_rotations(const uint8_t *opcodes, int64_t B, int shards, int64_t *bounds)
+{
+    auto cost = [&](int64_t g) -> int64_t {
+        const int op = opcodes ? opcodes[g] : TFHE_GATE_NAND;
+        const int rot = op == TFHE_GATE_MUX ? 2 : (op == TFHE_GATE_NOT || op == TFHE_GATE_COPY || op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1) ? 0 : 1;
+        return 1000 * (int64_t)rot + 1;
+    };
+    int64_t total = 0;
+    for (int64_t g = 0; g < B; g++) total += cost(g);
+    bounds[0] = 0;
+    int64_t cum = 0, g = 0;
+    for (int r = 1; r < shards; r++) {
+        // smallest g with cum(g) * shards >= total * r  (cum(g) = cost of gates [0, g))
+        while (g < B && cum * shards < total * r) { cum += cost(g); g++; }
+        bounds[r] = g;
+    }
+    bounds[shards] = B;
+}
+
 extern "C" {
 
 int32_t tfhe_abi_version(void) { return TFHE_MI355X_ABI_VERSION; }
@@ -141,6 +179,13 @@ int32_t tfhe_device_count(void)
 }
 
 const char *tfhe_last_error(const tfhe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t tfhe_shard_bounds(const uint8_t *opcodes, int64_t B, int32_t shards, int64_t *bounds)
+{
+    if (B < 0 || shards < 1 || !bounds) return TFHE_ERR_INVALID_ARG;
+    shard_bounds_by_rotations(opcodes, B, shards, bounds);
+    return TFHE_OK;
+}
 
 int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx **out_ctx)
 {
@@ -190,6 +235,7 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->map_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     std::vector<cplx> h;
     build_tables(h);
     if ((e = hipMalloc((void **)&c->d_tables, h.size() * sizeof(cplx))) != hipSuccess) return bail(e, "hipMalloc(tables)");
@@ -200,9 +246,38 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
     return TFHE_OK;
 }
 
+int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_ids, int32_t n_dev, tfhe_ctx **out_ctx)
+{
+    if (!params || !out_ctx || !device_ids) { g_create_error = "tfhe_ctx_create_multi: NULL argument"; return TFHE_ERR_INVALID_ARG; }
+    *out_ctx = nullptr;
+    if (n_dev < 1 || n_dev > 64) { g_create_error = "tfhe_ctx_create_multi: n_dev must be 1..64"; return TFHE_ERR_INVALID_ARG; }
+    tfhe_ctx *c = new tfhe_ctx();
+    c->P = *params;
+    c->device = device_ids[0];
+    for (int i = 0; i < n_dev; i++) {
+        tfhe_ctx *k = nullptr;
+        const int32_t rc = tfhe_ctx_create(params, device_ids[i], &k);
+        if (rc) {               // g_create_error holds the reason
+            tfhe_ctx_destroy(c);
+            return rc;
+        }
+        c->kids.push_back(k);
+    }
+    c->kid_ran.assign((size_t)n_dev, 0);
+    *out_ctx = c;
+    return TFHE_OK;
+}
+
+int32_t tfhe_ctx_device_count(const tfhe_ctx *ctx) { return !ctx ? -1 : ctx->multi() ? (int32_t)ctx->kids.size() : 1; }
+
 void tfhe_ctx_destroy(tfhe_ctx *c)
 {
     if (!c) return;
+    if (c->multi()) {
+        for (tfhe_ctx *k : c->kids) tfhe_ctx_destroy(k);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -214,11 +289,12 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
-    c->bara.release(); c->ext.release(); c->map.release(); c->margin.release(); c->abar.release();
+    c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->map_ev) (void)hipEventDestroy(c->map_ev);
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -230,6 +306,55 @@ int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out)
     return TFHE_OK;
 }
 
+}  // extern "C"
+
+__global__ void gather_rows_kernel(const int32_t *__restrict__ table, const int32_t *__restrict__ idx, int32_t *__restrict__ out, int n1)
+{
+    const size_t src = (size_t)idx[blockIdx.x], dst = blockIdx.x;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) out[dst * n1 + i] = table[src * n1 + i];
+}
+
+// ---- fan-out helpers --------------------------------------------------------------------------------
+// Runs fn(kid index) for every kid in `which` concurrently (one library-owned thread per extra kid; the calling
+// thread takes the first) and returns the first failing status, copying that kid's message.
+template <typename F>
+static int32_t fan_out(tfhe_ctx *c, const std::vector<int> &which, F &&fn)
+{
+    std::vector<int32_t> rcs(which.size(), TFHE_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < which.size(); i++) th.emplace_back([&, i] { rcs[i] = fn(which[i]); });
+    if (!which.empty()) rcs[0] = fn(which[0]);
+    for (auto &t : th) t.join();
+    std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
+    for (int k : which) c->kid_ran[(size_t)k] = 1;
+    for (size_t i = 0; i < which.size(); i++)
+        if (rcs[i]) return c->set_err(rcs[i], "device %d (kid %d): %s", c->kids[(size_t)which[i]]->device, which[i], c->kids[(size_t)which[i]]->err.c_str());
+    return TFHE_OK;
+}
+static std::vector<int> all_kids(const tfhe_ctx *c)
+{
+    std::vector<int> v(c->kids.size());
+    for (size_t i = 0; i < v.size(); i++) v[i] = (int)i;
+    return v;
+}
+
+// equal contiguous split of B rows for the entry points whose rows all cost the same
+template <typename F>
+static int32_t multi_rows(tfhe_ctx *c, int64_t B, F &&call)
+{
+    const int nk = (int)c->kids.size();
+    std::vector<int> which;
+    std::vector<int64_t> lo((size_t)nk), hi((size_t)nk);
+    for (int r = 0; r < nk; r++) {
+        lo[(size_t)r] = B * r / nk; hi[(size_t)r] = B * (r + 1) / nk;
+        if (hi[(size_t)r] > lo[(size_t)r]) which.push_back(r);
+    }
+    return fan_out(c, which, [&](int r) { return call(c->kids[(size_t)r], lo[(size_t)r], hi[(size_t)r] - lo[(size_t)r]); });
+}
+
+
+extern "C" {
+
 static size_t bk_poly_count(const tfhe_params &p) { return (size_t)p.n * p.bs_l * (p.k + 1) * (p.k + 1); }
 
 static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
@@ -237,6 +362,7 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!host) return c->set_err(TFHE_ERR_INVALID_ARG, "load_bootstrap_key: NULL key pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_bootstrap_key: context is multi-key, use tfhe_mk_load_*");
+    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return load_bk_common(c->kids[(size_t)k], host, bytes_in, is_c128); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npolys = bk_poly_count(c->P);
     const bool big = (c->P.N == kN2);
@@ -282,46 +408,102 @@ static size_t ks_word_count(const tfhe_params &p)
     return (size_t)p.k * p.N * p.ks_t * ((1u << p.ks_log2_base) - 1) * (size_t)(p.n + 1);
 }
 
+// Which keyswitch kernel family serves this context (decided when the key is loaded, so that only that family's key
+// layout stays resident): 4 = int8 MFMA (base 4, t = 8), 3 = tiled integer VALU (base 4, t multiple of 4), 1 = gather.
+static int pick_ks_mode(const tfhe_ctx *c)
+{
+    const int kNn = c->P.k * c->P.N;
+    const bool ok4 = c->P.ks_log2_base == 2 && c->P.ks_t == 8 && kNn % 128 == 0;
+    const bool ok3 = c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && kNn % KS3_SLICES == 0 && kNn / KS3_SLICES <= 128;
+    if (c->ks_variant == 4 && ok4) return 4;
+    if (c->ks_variant >= 3 && ok3) return 3;
+    return 1;
+}
+
 int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "load_keyswitch_key: NULL key pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_keyswitch_key: context is multi-key, use tfhe_mk_load_*");
+    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_load_keyswitch_key(c->kids[(size_t)k], ks); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t bytes = ks_word_count(c->P) * sizeof(int32_t);
-    if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; c->have_ks = false; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_ks, bytes));
-    HIP_TRY(c, hipMemcpy(c->d_ks, ks, bytes, hipMemcpyHostToDevice));
-    {   // row-padded copy: stride = n+1 rounded up to 4 words so that rows are 16-byte aligned
-        const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
-        const size_t rows = ks_word_count(c->P) / n1;
-        if (c->d_ksp) { (void)hipFree(c->d_ksp); c->d_ksp = nullptr; }
-        HIP_TRY(c, hipMalloc((void **)&c->d_ksp, rows * stride * 4));
-        HIP_TRY(c, hipMemset(c->d_ksp, 0, rows * stride * 4));
-        HIP_TRY(c, hipMemcpy2D(c->d_ksp, stride * 4, c->d_ks, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice));
-        c->ks_stride = (int)stride;
-    }
+    c->have_ks = false;
+    if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; }
+    if (c->d_ksp) { (void)hipFree(c->d_ksp); c->d_ksp = nullptr; }
     if (c->d_ks4) { (void)hipFree(c->d_ks4); c->d_ks4 = nullptr; }
-    if (c->P.ks_log2_base == 2 && c->P.ks_t == 8 && (c->P.k * c->P.N) % 4 == 0) {
-        const int kNn = c->P.k * c->P.N, wtiles = (c->P.n + 1 + 31) / 32;
-        const size_t frags = (size_t)kNn * wtiles * 4 * 64;
-        HIP_TRY(c, hipMalloc(&c->d_ks4, frags * 16));
-        hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)c->d_ks,
-                           (i32x4 *)c->d_ks4, c->P.n, kNn, wtiles);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->ks4_wtiles = wtiles;
-    }
+    int32_t *d_canon = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_canon, bytes));
+    const int mode = pick_ks_mode(c);
+    auto body = [&]() -> int32_t {
+        HIP_TRY(c, hipMemcpy(d_canon, ks, bytes, hipMemcpyHostToDevice));
+        if (mode == 3) {   // row-padded copy: stride = n+1 rounded up to 4 words so that rows are 16-byte aligned
+            const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
+            const size_t rows = ks_word_count(c->P) / n1;
+            HIP_TRY(c, hipMalloc((void **)&c->d_ksp, rows * stride * 4));
+            HIP_TRY(c, hipMemset(c->d_ksp, 0, rows * stride * 4));
+            HIP_TRY(c, hipMemcpy2D(c->d_ksp, stride * 4, d_canon, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice));
+            c->ks_stride = (int)stride;
+        } else if (mode == 4) {
+            const int kNn = c->P.k * c->P.N, wtiles = (c->P.n + 1 + 31) / 32;
+            const size_t frags = (size_t)kNn * wtiles * 4 * 64;
+            HIP_TRY(c, hipMalloc(&c->d_ks4, frags * 16));
+            hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_canon,
+                               (i32x4 *)c->d_ks4, c->P.n, kNn, wtiles);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->ks4_wtiles = wtiles;
+        }
+        return TFHE_OK;
+    };
+    const int32_t rc = body();
+    if (rc == TFHE_OK && mode == 1) c->d_ks = d_canon;       // the gather kernel reads the canonical layout
+    else (void)hipFree(d_canon);
+    if (rc) return rc;
+    c->ks_mode = mode;
     c->have_ks = true;
     return TFHE_OK;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------
+static int32_t prepare_diag(tfhe_ctx *c, size_t R, hipStream_t s, DiagArgs &d)
+{
+    d.margin_bits = nullptr; d.clk = nullptr;
+    c->diag_rows = 0;
+    if (!c->measure_margin) return TFHE_OK;
+    HIP_TRY(c, c->diag.reserve(R * 24));
+    HIP_TRY(c, hipMemsetAsync(c->diag.p, 0, R * 24, s));
+    d.margin_bits = (unsigned long long *)c->diag.p;
+    d.clk = d.margin_bits + R;
+    c->diag_rows = R;
+    return TFHE_OK;
+}
+
+#define BR_CASES(LAUNCH)                                                                                           \
+    switch (c->P.bs_l) {                                                                                           \
+    case 1: LAUNCH(1); break;                                                                                      \
+    case 2: LAUNCH(2); break;                                                                                      \
+    case 3: LAUNCH(3); break;                                                                                      \
+    case 4: LAUNCH(4); break;                                                                                      \
+    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);            \
+    }
+
+static void name_kernel(tfhe_ctx *c, const char *fmt, ...)
+{
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    c->last_kernel = buf;
+}
+
 static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
 {
-    c->margin_rows = 0;
     BrArgs a;
-    a.margin = nullptr;
+    int32_t rc = prepare_diag(c, R, s, a.diag);
+    if (rc) return rc;
+    const bool dg = c->measure_margin;
     a.bara = (const int32_t *)c->bara.p;
     a.bk = c->d_bk;
     a.ext = (int32_t *)c->ext.p;
@@ -329,83 +511,63 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.g = c->g;
     a.n = c->P.n;
     a.mu = mu;
+    const int L = c->P.bs_l;
     if (c->P.N == kN2) {
         Br2048Args b;
-        b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu;
+        b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu;
         const size_t ldsb = 2 * kN2 * 4 + (2 * kXchElems + 64) * sizeof(cplx);
-        switch (c->P.bs_l) {
-        case 1: hipLaunchKernelGGL((blind_rotate_kernel_n2048<1>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
-        case 2: hipLaunchKernelGGL((blind_rotate_kernel_n2048<2>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
-        case 3: hipLaunchKernelGGL((blind_rotate_kernel_n2048<3>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
-        case 4: hipLaunchKernelGGL((blind_rotate_kernel_n2048<4>), dim3((unsigned)R), dim3(128), ldsb, s, b); break;
-        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-        }
+#define LAUNCH_2048(LL)                                                                                            \
+        if (dg) hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, true>), dim3((unsigned)R), dim3(128), ldsb, s, b); \
+        else hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, false>), dim3((unsigned)R), dim3(128), ldsb, s, b)
+        BR_CASES(LAUNCH_2048)
+#undef LAUNCH_2048
         HIP_TRY(c, hipGetLastError());
+        name_kernel(c, "blind_rotate_kernel_n2048<%d>", L);
         return TFHE_OK;
     }
     if (c->P.k == 2) {
         const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-        switch (c->P.bs_l) {
-        case 1: hipLaunchKernelGGL((blind_rotate_kernel_k2<1>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
-        case 2: hipLaunchKernelGGL((blind_rotate_kernel_k2<2>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
-        case 3: hipLaunchKernelGGL((blind_rotate_kernel_k2<3>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
-        case 4: hipLaunchKernelGGL((blind_rotate_kernel_k2<4>), dim3((unsigned)R), dim3(64), ldsk, s, a); break;
-        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-        }
+#define LAUNCH_K2(LL)                                                                                              \
+        if (dg) hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, true>), dim3((unsigned)R), dim3(64), ldsk, s, a);  \
+        else hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false>), dim3((unsigned)R), dim3(64), ldsk, s, a)
+        BR_CASES(LAUNCH_K2)
+#undef LAUNCH_K2
         HIP_TRY(c, hipGetLastError());
+        name_kernel(c, "blind_rotate_kernel_k2<%d>", L);
         return TFHE_OK;
     }
-    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2 && !c->measure_margin) {
+    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2) {
         const size_t ldsw = 2 * kN * 4 + (2 * kXchElems + 4 * kM + 64) * sizeof(cplx);
-        switch (c->P.bs_l) {
-        case 1: hipLaunchKernelGGL((blind_rotate_kernel_w2<1>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
-        case 2: hipLaunchKernelGGL((blind_rotate_kernel_w2<2>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
-        case 3: hipLaunchKernelGGL((blind_rotate_kernel_w2<3>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
-        case 4: hipLaunchKernelGGL((blind_rotate_kernel_w2<4>), dim3((unsigned)R), dim3(128), ldsw, s, a); break;
-        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-        }
+#define LAUNCH_W2(LL)                                                                                              \
+        if (dg) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, true>), dim3((unsigned)R), dim3(128), ldsw, s, a); \
+        else hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false>), dim3((unsigned)R), dim3(128), ldsw, s, a)
+        BR_CASES(LAUNCH_W2)
+#undef LAUNCH_W2
         HIP_TRY(c, hipGetLastError());
-        return TFHE_OK;
-    }
-    if (c->measure_margin && c->P.k == 1 && c->P.N == kN) {   // diagnostics: same kernel, MARGIN instantiation
-        const size_t ldsm = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-        HIP_TRY(c, c->margin.reserve(R * sizeof(double)));
-        a.margin = (double *)c->margin.p;
-        switch (c->P.bs_l) {
-        case 1: hipLaunchKernelGGL((blind_rotate_kernel_v3<1, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
-        case 2: hipLaunchKernelGGL((blind_rotate_kernel_v3<2, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
-        case 3: hipLaunchKernelGGL((blind_rotate_kernel_v3<3, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
-        case 4: hipLaunchKernelGGL((blind_rotate_kernel_v3<4, 8, false, true>), dim3((unsigned)R), dim3(64), ldsm, s, a); break;
-        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-        }
-        HIP_TRY(c, hipGetLastError());
-        c->margin_rows = R;
+        name_kernel(c, "blind_rotate_kernel_w2<%d>", L);
         return TFHE_OK;
     }
     if (c->br_variant >= 2) {
         const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-#define LAUNCH_V3(LL, KK) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, KK, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
         const bool half = (c->br_variant == 3);
-        switch (c->P.bs_l) {
-        case 1: if (half) LAUNCH_V3(1, 8); else LAUNCH_V3(1, 16); break;
-        case 2: if (half) LAUNCH_V3(2, 8); else LAUNCH_V3(2, 16); break;
-        case 3: if (half) LAUNCH_V3(3, 8); else LAUNCH_V3(3, 16); break;
-        case 4: if (half) LAUNCH_V3(4, 8); else LAUNCH_V3(4, 16); break;
-        default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-        }
+#define LAUNCH_V3(LL)                                                                                              \
+        if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
+        else if (half) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
+        else if (dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
+        else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
+        BR_CASES(LAUNCH_V3)
 #undef LAUNCH_V3
         HIP_TRY(c, hipGetLastError());
+        name_kernel(c, "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
         return TFHE_OK;
     }
     const size_t lds = 2 * kN * 4 + kXchElems * sizeof(cplx);
-    switch (c->P.bs_l) {
-    case 1: hipLaunchKernelGGL((blind_rotate_kernel<1, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((blind_rotate_kernel<2, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
-    case 3: hipLaunchKernelGGL((blind_rotate_kernel<3, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((blind_rotate_kernel<4, 2>), dim3((unsigned)R), dim3(64), lds, s, a); break;
-    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);
-    }
+#define LAUNCH_V1(LL) hipLaunchKernelGGL((blind_rotate_kernel<LL, 2>), dim3((unsigned)R), dim3(64), lds, s, a)
+    BR_CASES(LAUNCH_V1)
+#undef LAUNCH_V1
     HIP_TRY(c, hipGetLastError());
+    name_kernel(c, "blind_rotate_kernel<%d,2>", L);
+    c->diag_rows = 0;      // the baseline kernel has no DIAG instantiation
     return TFHE_OK;
 }
 
@@ -419,7 +581,7 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     k.out = out;
     k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
     const int n1 = c->P.n + 1;
-    if (c->ks_variant == 4 && c->d_ks4 && k.kN % 128 == 0) {
+    if (c->ks_mode == 4) {
         Ks4Args a4;
         a4.ext = ext; a4.bmat = (const i32x4 *)c->d_ks4; a4.e0 = e0; a4.e1 = e1; a4.dst = dst; a4.out = out;
         a4.n = c->P.n; a4.kN = k.kN; a4.G = (int)G; a4.wtiles = c->ks4_wtiles;
@@ -442,8 +604,7 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
     }
-    if ((c->ks_variant == 3 || c->ks_variant == 4) && c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && k.kN % (KS3_SLICES * 1) == 0 &&
-        k.kN / KS3_SLICES <= 128) {
+    if (c->ks_mode == 3) {
         Ks3Args a3;
         a3.ext = ext; a3.ksp = c->d_ksp; a3.e0 = e0; a3.e1 = e1; a3.dst = dst; a3.out = out;
         a3.n = c->P.n; a3.kN = k.kN; a3.t = c->P.ks_t; a3.log2_base = 2; a3.stride = c->ks_stride; a3.G = (int)G;
@@ -461,12 +622,18 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     return TFHE_OK;
 }
 
-// Workspaces (bara, ext, abar, map, margin) are per context: work enqueued on another stream must have finished
-// before a call on stream `s` reuses them.
+// Workspaces (bara, ext, abar, map, diag) are per context: work a previous call enqueued (possibly on another stream)
+// must have finished before a call on stream `s` reuses them.  The previous call recorded done_ev at its end; making
+// `s` wait for that event orders the two without blocking the host and without keeping the caller's stream handle.
 static int32_t enter_stream(tfhe_ctx *c, hipStream_t s)
 {
-    if (c->last_stream && c->last_stream != s) HIP_TRY(c, hipStreamSynchronize(c->last_stream));
-    c->last_stream = s;
+    if (c->done_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->done_ev, 0));
+    return TFHE_OK;
+}
+static int32_t leave_stream(tfhe_ctx *c, hipStream_t s)
+{
+    HIP_TRY(c, hipEventRecord(c->done_ev, s));
+    c->done_pending = true;
     return TFHE_OK;
 }
 
@@ -484,16 +651,16 @@ static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
     return TFHE_OK;
 }
 
+static inline bool op_has_a(int op) { return !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1); }
+static inline bool op_has_b(int op) { return op_has_a(op) && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY); }
+
 // Common body of tfhe_gates_batch_dev (operands = rows g of three arrays, ia = ib = ic = io = NULL) and
-// tfhe_gates_level (operands = rows ia[g], ib[g], ic[g] of one wire table, result row io[g]).
+// tfhe_gates_level (operands = rows ia[g], ib[g], ic[g] of one wire table, result row io[g]; operands an opcode
+// does not read are replaced by row 0).
 static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, int64_t B, const int32_t *d_in0,
                          const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, const int32_t *ia, const int32_t *ib,
                          const int32_t *ic, const int32_t *io, hipStream_t s)
 {
-    {
-        const int32_t rc0 = enter_stream(c, s);
-        if (rc0) return rc0;
-    }
     // classify gates: rotations (R), keyswitches (G), trivial (T)
     size_t R = 0, G = 0, Tn = 0;
     bool need1 = false, need2 = false, need0 = false;
@@ -508,6 +675,10 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     if ((need0 && !d_in0) || (need1 && !d_in1) || (need2 && !d_in2))
         return c->set_err(TFHE_ERR_INVALID_ARG, "%s: an operand array required by the opcodes is NULL", who);
     if (R > 0 && (!c->have_bk || !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "%s: bootstrapping/keyswitch key not loaded", who);
+    {
+        const int32_t rc0 = enter_stream(c, s);
+        if (rc0) return rc0;
+    }
 
     // index maps, one pinned staging block:
     //   rot_a[R] | rot_b[R] | ks_e0[G] | ks_e1[G] | ks_dst[G] | triv_src[T] | triv_dst[T] | rot_kind[R] | triv_op[T]
@@ -521,7 +692,9 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
         size_t r = 0, k = 0, t = 0;
         for (int64_t g = 0; g < B; g++) {
             const int op = opcodes[g];
-            const int32_t ra = ia ? ia[g] : (int32_t)g, rb = ib ? ib[g] : (int32_t)g, rcw = ic ? ic[g] : (int32_t)g;
+            const int32_t ra = ia ? (op_has_a(op) ? ia[g] : 0) : (int32_t)g;
+            const int32_t rb = ib ? (op_has_b(op) ? ib[g] : 0) : (int32_t)g;
+            const int32_t rcw = ic ? (op == TFHE_GATE_MUX ? ic[g] : 0) : (int32_t)g;
             const int32_t ro = io ? io[g] : (int32_t)g;
             if (op == TFHE_GATE_MUX) {
                 h_ra[r] = ra; h_rb[r] = rb; h_kind[r] = 100;           // AND(x, y)      gates.jl:166
@@ -558,6 +731,8 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     if (R > 0) {
         rc = launch_blind_rotate(c, R, (int32_t)(1u << 29), s);   // mu = encode_message(1, 8), gates.jl:17
         if (rc) return rc;
+    } else {
+        c->diag_rows = 0;
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     if (G > 0) {
@@ -571,13 +746,20 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     }
     c->timing_valid = true;
     c->last_rotations = (int64_t)R;
-    return TFHE_OK;
+    return leave_stream(c, s);
 }
 
 int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *d_in0, const int32_t *d_in1,
                              const int32_t *d_in2, int32_t *d_out, int64_t B, void *stream)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) {
+        if (c->kids.size() != 1) return c->set_err(TFHE_ERR_STATE, "gates_batch_dev: device pointers belong to one device; use tfhe_gates_batch on a multi-device context");
+        const int32_t rc = tfhe_gates_batch_dev(c->kids[0], opcodes, d_in0, d_in1, d_in2, d_out, B, stream);
+        if (rc) c->err = c->kids[0]->err;
+        c->kid_ran[0] = 1;
+        return rc;
+    }
     if (B < 0 || (B > 0 && (!opcodes || !d_out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
     if (B == 0) { c->timing_valid = false; c->last_rotations = 0; return TFHE_OK; }
     if (B > (int64_t)1 << 30) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: B too large");
@@ -588,9 +770,12 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t 
 }
 
 // ---- levelised circuit execution on a device-resident wire table -------------------------
+// On a multi-device context the wire table lives on the first device (a level's gates exchange wires with every
+// other level, so sharding them would need a peer copy per level).
 int32_t tfhe_wires_alloc(tfhe_ctx *c, int64_t num_wires)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) { const int32_t rc = tfhe_wires_alloc(c->kids[0], num_wires); if (rc) c->err = c->kids[0]->err; return rc; }
     if (num_wires < 0 || num_wires > ((int64_t)1 << 30)) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_alloc: bad wire count");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -613,6 +798,7 @@ static int32_t wires_range_ok(tfhe_ctx *c, const char *who, int64_t first, int64
 int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32_t *host)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) { const int32_t rc = tfhe_wires_upload(c->kids[0], first, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
     int32_t rc = wires_range_ok(c, "wires_upload", first, count, host);
     if (rc || count == 0) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -625,6 +811,7 @@ int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32
 int32_t tfhe_wires_download(tfhe_ctx *c, int64_t first, int64_t count, int32_t *host)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) { const int32_t rc = tfhe_wires_download(c->kids[0], first, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
     int32_t rc = wires_range_ok(c, "wires_download", first, count, host);
     if (rc || count == 0) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -634,48 +821,85 @@ int32_t tfhe_wires_download(tfhe_ctx *c, int64_t first, int64_t count, int32_t *
     return TFHE_OK;
 }
 
+
+int32_t tfhe_wires_gather(tfhe_ctx *c, const int32_t *wires, int64_t count, int32_t *host)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) { const int32_t rc = tfhe_wires_gather(c->kids[0], wires, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
+    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "wires_gather: no wire table allocated");
+    if (count < 0 || (count > 0 && (!wires || !host))) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_gather: NULL argument or negative count");
+    if (count == 0) return TFHE_OK;
+    for (int64_t i = 0; i < count; i++)
+        if (wires[i] < 0 || wires[i] >= c->num_wires) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_gather: wire %d outside the table of %lld wires", wires[i], (long long)c->num_wires);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
+    const int n1 = c->P.n + 1;
+    int32_t rc = ensure_host_map(c, (size_t)count * 4);
+    if (rc) return rc;
+    memcpy(c->h_map, wires, (size_t)count * 4);
+    HIP_TRY(c, c->map.reserve((size_t)count * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->io[3].reserve((size_t)count * n1 * 4));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)count), dim3(256), 0, s, (const int32_t *)c->d_wires, (const int32_t *)c->map.p, (int32_t *)c->io[3].p, n1);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(host, c->io[3].p, (size_t)count * n1 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return TFHE_OK;
+}
+
 int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
                          const int32_t *out, int64_t B)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) { const int32_t rc = tfhe_gates_level(c->kids[0], opcodes, a, b, cc, out, B); if (rc) c->err = c->kids[0]->err; c->kid_ran[0] = 1; return rc; }
     if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_level: context is multi-key");
     if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "gates_level: no wire table allocated");
-    // every index in range; no wire both written and read inside one level (the level's gates are independent)
-    std::vector<uint8_t> mark((size_t)c->num_wires, 0);
+    // every index in range; no wire both written and read inside one level (the level's gates are independent).
+    // O(B) work whatever the size of the wire table: only the level's own output wires are hashed.
+    std::unordered_set<int32_t> written;
+    written.reserve((size_t)B * 2);
     auto bad = [&](int64_t v) { return v < 0 || v >= c->num_wires; };
     for (int64_t g = 0; g < B; g++) {
         const int op = opcodes[g];
         if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: bad opcode %d at gate %lld", op, (long long)g);
-        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
-        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
-        const bool has_c = (op == TFHE_GATE_MUX);
+        const bool has_a = op_has_a(op), has_b = op_has_b(op), has_c = (op == TFHE_GATE_MUX);
         if ((has_a && (!a || bad(a[g]))) || (has_b && (!b || bad(b[g]))) || (has_c && (!cc || bad(cc[g]))) || bad(out[g]))
             return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: wire index out of range (or missing operand array) at gate %lld", (long long)g);
-        if (mark[(size_t)out[g]] & 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: wire %d written twice in one level", out[g]);
-        mark[(size_t)out[g]] |= 1;
+        if (!written.insert(out[g]).second) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: wire %d written twice in one level", out[g]);
     }
     for (int64_t g = 0; g < B; g++) {
         const int op = opcodes[g];
-        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
-        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
-        if ((has_a && (mark[(size_t)a[g]] & 1)) || (has_b && (mark[(size_t)b[g]] & 1)) || (op == TFHE_GATE_MUX && (mark[(size_t)cc[g]] & 1)))
+        if ((op_has_a(op) && written.count(a[g])) || (op_has_b(op) && written.count(b[g])) || (op == TFHE_GATE_MUX && written.count(cc[g])))
             return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: gate %lld reads a wire written in the same level", (long long)g);
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    // operands of opcodes that ignore them get a valid dummy row (0)
-    std::vector<int32_t> ia((size_t)B), ib((size_t)B), ic((size_t)B);
-    for (int64_t g = 0; g < B; g++) {
-        const int op = opcodes[g];
-        const bool has_a = !(op == TFHE_GATE_CONST0 || op == TFHE_GATE_CONST1);
-        const bool has_b = has_a && !(op == TFHE_GATE_NOT || op == TFHE_GATE_COPY);
-        ia[(size_t)g] = has_a ? a[g] : 0;
-        ib[(size_t)g] = has_b ? b[g] : 0;
-        ic[(size_t)g] = op == TFHE_GATE_MUX ? cc[g] : 0;
-    }
-    return run_gates(c, "gates_level", opcodes, B, c->d_wires, c->d_wires, c->d_wires, c->d_wires, ia.data(), ib.data(), ic.data(), out,
+    // run_gates substitutes row 0 for operands an opcode does not read; a NULL index array (never read, checked above)
+    // is replaced by `out` only so that the pointer is non-NULL
+    return run_gates(c, "gates_level", opcodes, B, c->d_wires, c->d_wires, c->d_wires, c->d_wires, a ? a : out, b ? b : out, cc ? cc : out, out,
                      c->stream);
+}
+
+// fan-out of a host-buffer batch call: kid r takes gates [bounds[r], bounds[r+1])
+static int32_t multi_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                 int32_t *out, int64_t B)
+{
+    const int nk = (int)c->kids.size();
+    for (int64_t g = 0; g < B; g++)
+        if (opcodes[g] >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: bad opcode %d at gate %lld", opcodes[g], (long long)g);
+    std::vector<int64_t> bounds((size_t)nk + 1);
+    shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
+    std::vector<int> which;
+    for (int r = 0; r < nk; r++)
+        if (bounds[(size_t)r + 1] > bounds[(size_t)r]) which.push_back(r);
+    const size_t n1 = (size_t)c->P.n + 1;
+    return fan_out(c, which, [&](int r) {
+        const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
+        auto off = [&](const int32_t *p) { return p ? p + (size_t)s0 * n1 : nullptr; };
+        return tfhe_gates_batch(c->kids[(size_t)r], opcodes + s0, off(in0), off(in1), off(in2), out + (size_t)s0 * n1, cnt);
+    });
 }
 
 int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
@@ -684,7 +908,10 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
+    if (c->multi()) return multi_gates_batch(c, opcodes, in0, in1, in2, out, B);
     HIP_TRY(c, hipSetDevice(c->device));
+    // the staging buffers io[] are reused by this call: order the copies behind the previous call's kernels
+    { const int32_t rc0 = enter_stream(c, c->stream); if (rc0) return rc0; }
     const size_t bytes = (size_t)B * (c->P.n + 1) * 4;
     const int32_t *hin[3] = {in0, in1, in2};
     int32_t *din[3] = {nullptr, nullptr, nullptr};
@@ -708,6 +935,10 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
     if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "bootstrap_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "bootstrap_batch: context is multi-key");
+    if (c->multi()) {
+        const size_t wi = (size_t)c->P.n + 1, wo = with_keyswitch ? wi : (size_t)c->P.k * c->P.N + 1;
+        return multi_rows(c, B, [&](tfhe_ctx *k, int64_t s0, int64_t cnt) { return tfhe_bootstrap_batch(k, mu, in + (size_t)s0 * wi, out + (size_t)s0 * wo, cnt, with_keyswitch); });
+    }
     if (!c->have_bk || (with_keyswitch && !c->have_ks)) return c->set_err(TFHE_ERR_NO_KEY, "bootstrap_batch: key not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -742,6 +973,8 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
         HIP_TRY(c, hipEventRecord(c->ev[3], s));
         HIP_TRY(c, hipMemcpyAsync(out, c->ext.p, (size_t)B * (kNn + 1) * 4, hipMemcpyDeviceToHost, s));
     }
+    rc = leave_stream(c, s);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->timing_valid = true;
     c->last_rotations = B;
@@ -754,6 +987,10 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "keyswitch_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "keyswitch_batch: context is multi-key");
+    if (c->multi()) {
+        const size_t wi = (size_t)c->P.k * c->P.N + 1, wo = (size_t)c->P.n + 1;
+        return multi_rows(c, B, [&](tfhe_ctx *k, int64_t s0, int64_t cnt) { return tfhe_keyswitch_batch(k, in + (size_t)s0 * wi, out + (size_t)s0 * wo, cnt); });
+    }
     if (!c->have_ks) return c->set_err(TFHE_ERR_NO_KEY, "keyswitch_batch: keyswitch key not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -775,9 +1012,12 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, out_bytes, hipMemcpyDeviceToHost, s));
+    rc = leave_stream(c, s);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->timing_valid = true;
     c->last_rotations = 0;
+    c->diag_rows = 0;
     return TFHE_OK;
 }
 
@@ -787,6 +1027,7 @@ int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t p
     if (!bk) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: NULL key pointer");
     if (parties < 2 || parties > 8 || c->P.parties < parties)
         return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
+    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_mk_load_bootstrap_key_i32(c->kids[(size_t)k], bk, parties); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t per = (size_t)2 * c->P.bs_l * parties + 2 * c->P.bs_l;
     const size_t npolys = (size_t)parties * c->P.n * per;
@@ -815,33 +1056,43 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
         return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: parties must be 2..8 and not exceed the context's max_parties");
     if (c->P.ks_log2_base != 2 || c->P.ks_t % 4 != 0 || c->P.N % KS3_SLICES != 0 || c->P.N / KS3_SLICES > 128)
         return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: keyswitch base must be 4 and t a multiple of 4");
+    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_mk_load_keyswitch_key(c->kids[(size_t)k], ks, parties); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
     const size_t rows = (size_t)c->P.N * c->P.ks_t * ((1u << c->P.ks_log2_base) - 1);   // per party (k = 1)
-    if (c->d_mk_ksp) { (void)hipFree(c->d_mk_ksp); c->d_mk_ksp = nullptr; c->have_mk_ks = false; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_mk_ksp, (size_t)parties * rows * stride * 4));
-    HIP_TRY(c, hipMemset(c->d_mk_ksp, 0, (size_t)parties * rows * stride * 4));
-    HIP_TRY(c, hipMemcpy2D(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice));
-    c->mk_ksp_words = rows * stride;
-    c->ks_stride = (int)stride;
+    c->have_mk_ks = false;
+    if (c->d_mk_ksp) { (void)hipFree(c->d_mk_ksp); c->d_mk_ksp = nullptr; }
     if (c->d_mk_ks4) { (void)hipFree(c->d_mk_ks4); c->d_mk_ks4 = nullptr; }
-    if (c->P.ks_t == 8) {   // MFMA fragments per party (keyswitch_kernel_v4)
+    const int mode = (c->ks_variant == 4 && c->P.ks_t == 8) ? 4 : 3;
+    if (mode == 3) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_mk_ksp, (size_t)parties * rows * stride * 4));
+        HIP_TRY(c, hipMemset(c->d_mk_ksp, 0, (size_t)parties * rows * stride * 4));
+        HIP_TRY(c, hipMemcpy2D(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice));
+        c->mk_ksp_words = rows * stride;
+        c->ks_stride = (int)stride;
+    } else {   // MFMA fragments per party (keyswitch_kernel_v4)
         const int wtiles = (c->P.n + 1 + 31) / 32;
         const size_t frags = (size_t)c->P.N * wtiles * 4 * 64, words = rows * n1;
         int32_t *d_tmp = nullptr;
         HIP_TRY(c, hipMalloc((void **)&d_tmp, words * 4));
-        HIP_TRY(c, hipMalloc(&c->d_mk_ks4, (size_t)parties * frags * 16));
-        for (int p = 0; p < parties; p++) {
-            HIP_TRY(c, hipMemcpy(d_tmp, ks + (size_t)p * words, words * 4, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_tmp,
-                               (i32x4 *)c->d_mk_ks4 + (size_t)p * frags, c->P.n, c->P.N, wtiles);
-            HIP_TRY(c, hipGetLastError());
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-        (void)hipFree(d_tmp);
+        auto body = [&]() -> int32_t {
+            HIP_TRY(c, hipMalloc(&c->d_mk_ks4, (size_t)parties * frags * 16));
+            for (int p = 0; p < parties; p++) {
+                HIP_TRY(c, hipMemcpy(d_tmp, ks + (size_t)p * words, words * 4, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_tmp,
+                                   (i32x4 *)c->d_mk_ks4 + (size_t)p * frags, c->P.n, c->P.N, wtiles);
+                HIP_TRY(c, hipGetLastError());
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+            return TFHE_OK;
+        };
+        const int32_t rc = body();
+        (void)hipFree(d_tmp);        // also on the error path
+        if (rc) return rc;
         c->mk_ks4_frags = frags;
         c->ks4_wtiles = wtiles;
     }
+    c->ks_mode = mode;
     c->have_mk_ks = true;
     return TFHE_OK;
 }
@@ -851,6 +1102,12 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!in0 || !in1 || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_gate_nand_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
+    if (c->multi()) {
+        const tfhe_ctx *k0 = c->kids[0];
+        if (!k0->have_mk_bk || !k0->have_mk_ks) return c->set_err(TFHE_ERR_NO_KEY, "mk_gate_nand_batch: multi-key keys not loaded");
+        const size_t w = (size_t)k0->mk_parties * c->P.n + 1;
+        return multi_rows(c, B, [&](tfhe_ctx *k, int64_t s0, int64_t cnt) { return tfhe_mk_gate_nand_batch(k, in0 + (size_t)s0 * w, in1 + (size_t)s0 * w, out + (size_t)s0 * w, cnt); });
+    }
     if (!c->have_mk_bk || !c->have_mk_ks) return c->set_err(TFHE_ERR_NO_KEY, "mk_gate_nand_batch: multi-key keys not loaded");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -883,27 +1140,39 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     MkBrArgs a;
+    rc = prepare_diag(c, (size_t)B, s, a.diag);
+    if (rc) return rc;
+    const bool dg = c->measure_margin;
     a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
     a.n = n; a.mu = (int32_t)(1u << 29);
     const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
     if (special) {
+#define LAUNCH_MK(LL)                                                                                              \
+        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, true>), dim3((unsigned)B), dim3(64), lds, s, a);   \
+        else hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, false>), dim3((unsigned)B), dim3(64), lds, s, a)
         switch (c->P.bs_l) {
-        case 2: hipLaunchKernelGGL((mk_blind_rotate_kernel<2>), dim3((unsigned)B), dim3(64), lds, s, a); break;
-        case 3: hipLaunchKernelGGL((mk_blind_rotate_kernel<3>), dim3((unsigned)B), dim3(64), lds, s, a); break;
-        default: hipLaunchKernelGGL((mk_blind_rotate_kernel<4>), dim3((unsigned)B), dim3(64), lds, s, a); break;
+        case 2: LAUNCH_MK(2); break;
+        case 3: LAUNCH_MK(3); break;
+        default: LAUNCH_MK(4); break;
         }
+#undef LAUNCH_MK
+        name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
     } else {
         MkGenArgs ga;
-        ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
-        if (lds > 64 * 1024)
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mk_blind_rotate_kernel_general, dim3((unsigned)B), dim3(64), lds, s, ga);
+        ga.diag = a.diag; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
+        if (lds > 64 * 1024) {
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (dg) hipLaunchKernelGGL(mk_blind_rotate_kernel_general<true>, dim3((unsigned)B), dim3(64), lds, s, ga);
+        else hipLaunchKernelGGL(mk_blind_rotate_kernel_general<false>, dim3((unsigned)B), dim3(64), lds, s, ga);
+        name_kernel(c, "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     // mk_keyswitch (mk_internals.jl:397-411): per party a single-key keyswitch of its mask column with b = 0
-    if (c->ks_variant == 4 && c->d_mk_ks4) {
+    if (c->ks_mode == 4) {
         Ks4Args a4;
         a4.ext = (const int32_t *)c->ext.p; a4.e0 = d_gate; a4.e1 = nullptr; a4.dst = nullptr; a4.out = (int32_t *)c->io[3].p;
         a4.n = n; a4.kN = kN; a4.G = (int)B; a4.wtiles = c->ks4_wtiles;
@@ -917,28 +1186,24 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
             a4.bmat = (const i32x4 *)c->d_mk_ks4 + (size_t)p * c->mk_ks4_frags;
             hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((B + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
         }
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(c->ev[3], s));
-        HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        c->timing_valid = true;
-        c->last_rotations = B;
-        return TFHE_OK;
-    }
-    Ks3Args k3;
-    k3.ext = (const int32_t *)c->ext.p; k3.e0 = d_gate; k3.e1 = nullptr; k3.dst = nullptr; k3.out = (int32_t *)c->io[3].p;
-    k3.n = n; k3.kN = kN; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
-    k3.in_stride = ew; k3.in_b = NP * kN; k3.out_stride = nw; k3.out_b = NP * n;
-    k3.in_off = 0; k3.out_off = 0; k3.ksp = c->d_mk_ksp;
-    hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)B), dim3(256), 0, s, k3);
-    const unsigned tiles = (unsigned)((B + KS3_G - 1) / KS3_G);
-    for (int p = 0; p < NP; p++) {
-        k3.in_off = p * kN; k3.out_off = p * n; k3.ksp = c->d_mk_ksp + (size_t)p * c->mk_ksp_words;
-        hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, k3);
+    } else {
+        Ks3Args k3;
+        k3.ext = (const int32_t *)c->ext.p; k3.e0 = d_gate; k3.e1 = nullptr; k3.dst = nullptr; k3.out = (int32_t *)c->io[3].p;
+        k3.n = n; k3.kN = kN; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
+        k3.in_stride = ew; k3.in_b = NP * kN; k3.out_stride = nw; k3.out_b = NP * n;
+        k3.in_off = 0; k3.out_off = 0; k3.ksp = c->d_mk_ksp;
+        hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)B), dim3(256), 0, s, k3);
+        const unsigned tiles = (unsigned)((B + KS3_G - 1) / KS3_G);
+        for (int p = 0; p < NP; p++) {
+            k3.in_off = p * kN; k3.out_off = p * n; k3.ksp = c->d_mk_ksp + (size_t)p * c->mk_ksp_words;
+            hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, k3);
+        }
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, s));
+    rc = leave_stream(c, s);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->timing_valid = true;
     c->last_rotations = B;
@@ -948,6 +1213,19 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
 {
     if (!c || !ms) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) {      // the shards ran concurrently: the batch took as long as the slowest of them
+        float worst = -1.f;
+        for (size_t k = 0; k < c->kids.size(); k++) {
+            if (!c->kid_ran[k]) continue;
+            float v = 0.f;
+            const int32_t rc = tfhe_last_timing_ms(c->kids[k], which, &v);
+            if (rc) { c->err = c->kids[k]->err; return rc; }
+            worst = v > worst ? v : worst;
+        }
+        if (worst < 0.f) return c->set_err(TFHE_ERR_STATE, "last_timing: no batch call recorded");
+        *ms = worst;
+        return TFHE_OK;
+    }
     if (!c->timing_valid) return c->set_err(TFHE_ERR_STATE, "last_timing: no batch call recorded");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipEventSynchronize(c->ev[3]));
@@ -962,26 +1240,101 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
     return TFHE_OK;
 }
 
-int64_t tfhe_last_rotation_count(const tfhe_ctx *c) { return c ? c->last_rotations : -1; }
+int64_t tfhe_last_rotation_count(const tfhe_ctx *c)
+{
+    if (!c) return -1;
+    if (c->multi()) {
+        int64_t sum = 0;
+        for (size_t k = 0; k < c->kids.size(); k++) if (c->kid_ran[k]) sum += c->kids[k]->last_rotations;
+        return sum;
+    }
+    return c->last_rotations;
+}
+
+const char *tfhe_last_kernel_name(const tfhe_ctx *c)
+{
+    if (!c) return "";
+    if (c->multi()) {
+        for (size_t k = 0; k < c->kids.size(); k++) if (c->kid_ran[k]) return c->kids[k]->last_kernel.c_str();
+        return "";
+    }
+    return c->last_kernel.c_str();
+}
+
+// reads the DIAG records of the last batch call: worst rounding margin and the median in-kernel clock
+static int32_t read_diag(tfhe_ctx *c, double *worst, double *mhz)
+{
+    if (!c->diag_rows) return c->set_err(TFHE_ERR_STATE, "diagnostics: enable tfhe_set_option(\"measure_margin\", 1) before the batch call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->done_pending) HIP_TRY(c, hipEventSynchronize(c->done_ev));
+    const size_t R = c->diag_rows;
+    std::vector<unsigned long long> h(3 * R);
+    HIP_TRY(c, hipMemcpy(h.data(), c->diag.p, 3 * R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double m = 0;
+    for (size_t r = 0; r < R; r++) {
+        double v;
+        memcpy(&v, &h[r], 8);
+        m = v > m ? v : m;
+    }
+    if (worst) *worst = m;
+    if (mhz) {
+        std::vector<double> f;
+        f.reserve(R);
+        for (size_t r = 0; r < R; r++)
+            if (h[R + 2 * r + 1] > 0) f.push_back((double)h[R + 2 * r] / (double)h[R + 2 * r + 1] * 100.0);
+        if (f.empty()) return c->set_err(TFHE_ERR_STATE, "diagnostics: no clock record");
+        std::nth_element(f.begin(), f.begin() + (long)(f.size() / 2), f.end());
+        *mhz = f[f.size() / 2];
+    }
+    return TFHE_OK;
+}
 
 int32_t tfhe_last_rounding_margin(tfhe_ctx *c, double *worst)
 {
     if (!c || !worst) return TFHE_ERR_INVALID_ARG;
-    if (!c->margin_rows) return c->set_err(TFHE_ERR_STATE, "last_rounding_margin: enable tfhe_set_option(\"measure_margin\", 1) before the batch call (N = 1024, k = 1)");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<double> h(c->margin_rows);
-    HIP_TRY(c, hipMemcpy(h.data(), c->margin.p, c->margin_rows * sizeof(double), hipMemcpyDeviceToHost));
-    double m = 0;
-    for (double v : h) m = v > m ? v : m;
-    *worst = m;
-    return TFHE_OK;
+    if (c->multi()) {
+        double m = -1;
+        for (size_t k = 0; k < c->kids.size(); k++) {
+            if (!c->kid_ran[k]) continue;
+            double v = 0;
+            const int32_t rc = read_diag(c->kids[k], &v, nullptr);
+            if (rc) { c->err = c->kids[k]->err; return rc; }
+            m = v > m ? v : m;
+        }
+        if (m < 0) return c->set_err(TFHE_ERR_STATE, "last_rounding_margin: no batch call recorded");
+        *worst = m;
+        return TFHE_OK;
+    }
+    return read_diag(c, worst, nullptr);
+}
+
+int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *c, double *mhz)
+{
+    if (!c || !mhz) return TFHE_ERR_INVALID_ARG;
+    if (c->multi()) {
+        for (size_t k = 0; k < c->kids.size(); k++) {
+            if (!c->kid_ran[k]) continue;
+            const int32_t rc = read_diag(c->kids[k], nullptr, mhz);
+            if (rc) c->err = c->kids[k]->err;
+            return rc;
+        }
+        return c->set_err(TFHE_ERR_STATE, "last_kernel_clock: no batch call recorded");
+    }
+    return read_diag(c, nullptr, mhz);
 }
 
 int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!name || !*name) return TFHE_OK;
+    if (c->multi()) {
+        for (tfhe_ctx *k : c->kids) {
+            const int32_t rc = tfhe_set_option(k, name, value);
+            if (rc) { c->err = k->err; return rc; }
+        }
+        return TFHE_OK;
+    }
     if (!strcmp(name, "br_variant")) {
         if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 1, 2 or 3");
         c->br_variant = (int)value;
@@ -997,6 +1350,9 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "ks_variant")) {
         if (value != 1 && value != 3 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 3 or 4");
+        // only the selected family's key layout is kept on the device: choose before loading the keyswitch key
+        if ((c->have_ks || c->have_mk_ks) && (int)value != c->ks_variant)
+            return c->set_err(TFHE_ERR_STATE, "set_option: ks_variant must be chosen before the keyswitch key is loaded (reload the key after changing it)");
         c->ks_variant = (int)value;
         return TFHE_OK;
     }

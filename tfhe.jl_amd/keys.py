@@ -92,12 +92,15 @@ class CloudKey:
         self._engines = {}
 
     def engine(self, device=0) -> "_lib.Engine":
-        e = self._engines.get(device)
+        """`device`: a device id, or a sequence of ids for a multi-device context (every batch call is then split
+        over those GPUs inside the library: the analogue of `gate_nand.(ck, xs, ys)` over a whole node)."""
+        key = device if np.ndim(device) == 0 else tuple(int(d) for d in device)
+        e = self._engines.get(key)
         if e is None:
-            e = _lib.Engine(self.params, device)
+            e = _lib.Engine(self.params, device) if np.ndim(device) == 0 else _lib.Engine(self.params, devices=list(key))
             e.load_bootstrap_key(self.bootstrap_key)
             e.load_keyswitch_key(self.keyswitch_key)
-            self._engines[device] = e
+            self._engines[key] = e
         return e
 
     def close(self):

@@ -99,12 +99,13 @@ class MKCloudKey:
         self._engines = {}
 
     def engine(self, device=0):
-        e = self._engines.get(device)
+        key = device if np.ndim(device) == 0 else tuple(int(d) for d in device)
+        e = self._engines.get(key)
         if e is None:
-            e = _lib.Engine(self.params, device)
+            e = _lib.Engine(self.params, device) if np.ndim(device) == 0 else _lib.Engine(self.params, devices=list(key))
             e.mk_load_bootstrap_key(self.bootstrap_key, self.parties)
             e.mk_load_keyswitch_key(self.keyswitch_key, self.parties)
-            self._engines[device] = e
+            self._engines[key] = e
         return e
 
     def close(self):

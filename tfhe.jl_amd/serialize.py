@@ -88,15 +88,16 @@ class LoadedCloudKey:
 
     def engine(self, device=0):
         from . import _lib
-        e = self._engines.get(device)
+        key = device if np.ndim(device) == 0 else tuple(int(d) for d in device)
+        e = self._engines.get(key)
         if e is None:
-            e = _lib.Engine(self.params, device)
+            e = _lib.Engine(self.params, device) if np.ndim(device) == 0 else _lib.Engine(self.params, devices=list(key))
             if self.bootstrap_key is not None:
                 e.load_bootstrap_key(self.bootstrap_key)
             else:
                 e.load_bootstrap_key_spectra(self.bootstrap_spectra)
             e.load_keyswitch_key(self.keyswitch_key)
-            self._engines[device] = e
+            self._engines[key] = e
         return e
 
     def close(self):
