@@ -125,12 +125,15 @@ def _mk_check(eng, o, x, y, expect_kernel):
 
 @pytest.mark.parametrize("l", [2, 3, 4])
 def test_mk_two_party_kernel_every_l(tfhe, orc, l):
-    """mk_blind_rotate_kernel<l> (2 parties; l = 4, beta = 7 is mktfhe_parameters_2party, mk_api.jl:4-10)."""
+    """mk_blind_rotate_kernel_w3<l> (three waves per rotation, the default) and mk_blind_rotate_kernel<l> (one wave):
+    2 parties; l = 4, beta = 7 is mktfhe_parameters_2party, mk_api.jl:4-10."""
     p, rng, sks, ck, o = _mk(tfhe, orc, 2, l, 7, 12, 2, 60 + l)
     eng = ck.engine(0)
     x, y = _words(rng, 5, 2 * 12 + 1), _words(rng, 5, 2 * 12 + 1)[::-1].copy()
     x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
     y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_w3<{l}>")
+    eng.set_option("mk_variant", 1)
     _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel<{l}>")
     ck.close()
 
@@ -200,7 +203,7 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
 
 
 def test_config5_mk_two_party_1024(tfhe, orc):
-    """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel<4>.
+    """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel_w3<4>.
     64 sampled rows equal the oracle word for word (decrypt-level MK checks are ~0.2 %/gate noisy by design of the
     scheme's parameters, SURVEY §4: at least 98.5 % must decrypt to NAND)."""
     p = tfhe.mktfhe_parameters_2party
@@ -216,7 +219,7 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     m1, m2 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     x, y = tfhe.mk_encrypt(rng, sks, m1), tfhe.mk_encrypt(rng, sks, m2)
     got = eng.mk_gate_nand(x, y)
-    assert eng.last_kernel_name() == "mk_blind_rotate_kernel<4>"
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w3<4>"
     assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.985
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
@@ -225,6 +228,9 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     margin = eng.last_rounding_margin()
     eng.set_option("measure_margin", 0)
     assert np.array_equal(again, got[:128]) and 0.0 < margin < 0.25, margin
+    eng.set_option("mk_variant", 1)                 # the one-wave-per-rotation kernel gives the same words
+    assert np.array_equal(eng.mk_gate_nand(x[:96], y[:96]), got[:96]) and eng.last_kernel_name() == "mk_blind_rotate_kernel<4>"
+    eng.set_option("mk_variant", 3)
     # the fan-out context (two device contexts on this one GPU) gives the same words
     e2 = ck.engine([0, 0])
     assert e2.device_count() == 2
@@ -273,38 +279,76 @@ def test_multi_device_context_equals_single(tfhe, orc, keys80):
         tfhe.Engine(K.params, devices=[0, 99])                                   # one bad id fails the whole create
 
 
+class _Hip:
+    """The few HIP runtime calls the stream test needs, through ctypes on the runtime the engine already loaded
+    (importing torch here would bring a second HIP runtime into the process)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+        for f in ("hipStreamCreate", "hipStreamDestroy", "hipStreamSynchronize", "hipMalloc", "hipFree", "hipMemcpy", "hipDeviceSynchronize", "hipSetDevice"):
+            getattr(self.lib, f).restype = C.c_int
+
+    def ok(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def stream(self):
+        h = self.C.c_void_p()
+        self.ok(self.lib.hipStreamCreate(self.C.byref(h)))
+        return h
+
+    def upload(self, a):
+        p = self.C.c_void_p()
+        self.ok(self.lib.hipMalloc(self.C.byref(p), self.C.c_size_t(a.nbytes)))
+        self.ok(self.lib.hipMemcpy(p, a.ctypes.data_as(self.C.c_void_p), self.C.c_size_t(a.nbytes), 1))
+        return p
+
+    def alloc(self, nbytes):
+        p = self.C.c_void_p()
+        self.ok(self.lib.hipMalloc(self.C.byref(p), self.C.c_size_t(nbytes)))
+        return p
+
+    def download(self, p, shape):
+        out = np.empty(shape, np.int32)
+        self.ok(self.lib.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), p, self.C.c_size_t(out.nbytes), 2))
+        return out
+
+
 def test_alternating_streams_share_one_context(tfhe, orc, keys80):
     """Batch calls issued on two different HIP streams against ONE context (shared workspaces): each call waits, on the
     device, for the context-owned event the previous call recorded — no host block, no foreign stream handle kept.
-    One of the streams is dropped and replaced between calls.  All outputs equal the oracle."""
-    import gc
-    import torch
+    One of the streams is synchronised, DESTROYED and replaced between calls (legal for the caller; a stored handle
+    would dangle).  All outputs equal the oracle."""
     K = keys80
     eng = K.ck.engine(0)
-    dev = torch.device("cuda", 0)
+    hip = _Hip()
+    hip.ok(hip.lib.hipSetDevice(0))
     rng = np.random.default_rng(77)
     B = 600                     # > 512 rotations: the one-wave-per-rotation kernel, ~2 ms per call
     ops = np.zeros(B, np.uint8)
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    streams = [hip.stream(), hip.stream()]
     batches = []
     for it in range(6):
         hx = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data
         hy = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data
+        dx, dy, dout = hip.upload(hx), hip.upload(hy), hip.alloc(B * 501 * 4)
         s = streams[it & 1]
-        with torch.cuda.stream(s):
-            dx, dy = torch.from_numpy(hx).to(dev, non_blocking=False), torch.from_numpy(hy).to(dev, non_blocking=False)
-            dout = torch.empty((B, 501), dtype=torch.int32, device=dev)
-        s.synchronize()
-        eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), 0, dout.data_ptr(), B, s.cuda_stream)     # returns before the kernels finish
-        batches.append((hx, hy, dx, dy, dout, s))
-        if it == 3:             # the caller may drop a stream it has synchronised; the context must not care
-            streams[1].synchronize()
-            streams[1] = torch.cuda.Stream(dev)
-            gc.collect()
-    torch.cuda.synchronize(dev)
-    for hx, hy, dx, dy, dout, s in batches:
-        idx = [0, 1, B // 2, B - 1]
-        assert np.array_equal(dout.cpu().numpy()[idx], K.oracle.gates(ops[idx], hx[idx], hy[idx], nthreads=4))
+        eng.gates_dev(ops, dx.value, dy.value, 0, dout.value, B, s.value)     # returns before the kernels finish
+        batches.append((hx, hy, dx, dy, dout))
+        if it == 3:             # the caller may destroy a stream it has synchronised; the context must not care
+            hip.ok(hip.lib.hipStreamSynchronize(streams[1]))
+            hip.ok(hip.lib.hipStreamDestroy(streams[1]))
+            streams[1] = hip.stream()
+    hip.ok(hip.lib.hipDeviceSynchronize())
+    idx = [0, 1, B // 2, B - 1]
+    for hx, hy, dx, dy, dout in batches:
+        got = hip.download(dout, (B, 501))
+        assert np.array_equal(got[idx], K.oracle.gates(ops[idx], hx[idx], hy[idx], nthreads=4))
+        for p in (dx, dy, dout):
+            hip.ok(hip.lib.hipFree(p))
+    for s in streams:
+        hip.ok(hip.lib.hipStreamDestroy(s))
 
 
 def test_wires_gather_any_order(tfhe, keys80):

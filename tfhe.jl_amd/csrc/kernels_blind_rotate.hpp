@@ -522,6 +522,185 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
+// ---- multi-key blind rotation, 2 parties, THREE waves per rotation ---------------------------------------------
+// BASELINE config 5 is 1024 rotations: with one wave per rotation that is one wave per SIMD, each running 12 forward
+// and 3 inverse transforms per step back to back (a lone wave issues FP64 at half the SIMD's rate).  Here wave s
+// (s = 0, 1: party masks a_0, a_1; s = 2: body b) owns accumulator polynomial s: it rotates and decomposes only its own
+// polynomial, runs its L forward transforms and multiplies them into (mk_internals.jl:371-385)
+//     its OWN new polynomial          party wave: y[p, party]        other mask: y[p, party]        body: c0[p]
+//     the party's new mask (partial)                                  other mask: y[p, s]            body: c1[p]
+//     the new body (partial)          party wave: x[p, party]        other mask: x[p, s]
+// then the partial sums for the party's mask and for the body are handed over through LDS (two barriers per step), the
+// two owners add what they receive, and every wave inverse-transforms and updates its own polynomial.  Same words as
+// mk_blind_rotate_kernel; 4 (+1) transforms per wave and step instead of 15.
+enum { MK3_PARTY = 0, MK3_OTHER = 1, MK3_BODY = 2 };
+
+template <int L, int ROLE, bool MARGIN>
+__device__ __forceinline__ void mk3_party_steps(int lane, int party, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds /* own polynomial */,
+                                                cplx *xch, cplx *xfer, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
+{
+    constexpr int NP = 2;
+    constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
+    const int beta = P.g.log2_base;
+    const int s = ROLE == MK3_PARTY ? party : ROLE == MK3_OTHER ? 1 - party : NP;   // this wave's source polynomial
+    // hand-off slots (512 cplx each): 0 = body -> party, 1 = other -> party, 2 = party -> body, 3 = other -> body
+    cplx *to_party = xfer + (ROLE == MK3_BODY ? 0 : 1) * kM;
+    cplx *to_body = xfer + (ROLE == MK3_PARTY ? 2 : 3) * kM;
+    int a_next = bara[party * P.n] & (2 * kN - 1);
+#pragma unroll 1
+    for (int j = 0; j < P.n; j++) {
+        const int a = a_next;
+        a_next = bara[party * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
+        const cplx *key = P.bk + ((size_t)party * P.n + j) * PER * kM + lane;
+        cplx own[8], pa[8], pb[8];                 // own polynomial; partial for the party's mask; partial for the body
+#pragma unroll
+        for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); pa[q] = mk(0.0, 0.0); pb[q] = mk(0.0, 0.0); }
+        int32_t temp[16];
+        {
+            int32_t cur[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
+            int a_here = a;
+            asm volatile("" : "+v"(a_here));   // keeps the rotate addresses from being hoisted out of the step loop
+            rotate_sub2(lane, a_here, acc_lds, cur, P.g.offset, xormask, temp);
+        }
+#pragma unroll 1
+        for (int p = 0; p < L; p++) {
+            // key polys of this transform (mk_internals.jl:371-385), the first two requested before the FFT
+            const cplx *k_own, *k_a = nullptr, *k_b = nullptr;
+            if (ROLE == MK3_PARTY) {
+                k_own = key + (size_t)(L * NP + p * NP + s) * kM;            // y[p, party]  -> a'_party
+                k_b = key + (size_t)(p * NP + s) * kM;                       // x[p, party]  -> b'
+            } else if (ROLE == MK3_OTHER) {
+                k_own = key + (size_t)(L * NP + p * NP + party) * kM;        // y[p, party]  -> a'_s
+                k_a = key + (size_t)(L * NP + p * NP + s) * kM;              // y[p, s]      -> a'_party
+                k_b = key + (size_t)(p * NP + s) * kM;                       // x[p, s]      -> b'
+            } else {
+                k_own = key + (size_t)(2 * L * NP + p) * kM;                 // c0[p]        -> b'
+                k_a = key + (size_t)(2 * L * NP + L + p) * kM;               // c1[p]        -> a'_party
+            }
+            // (the wave with three products keeps one key poly in flight across the FFT, the others two)
+            cplx k0[8], k1[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) k0[k2] = k_own[k2 * 64];
+            if (ROLE != MK3_OTHER) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) k1[k2] = (ROLE == MK3_PARTY ? k_b : k_a)[k2 * 64];
+            }
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            if (ROLE == MK3_OTHER) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) k1[k2] = k_a[k2 * 64];
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = cfma(x[k2], k0[k2], own[k2]);
+            if (ROLE == MK3_PARTY) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) pb[k2] = cfma(x[k2], k1[k2], pb[k2]);
+            } else if (ROLE == MK3_BODY) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) pa[k2] = cfma(x[k2], k1[k2], pa[k2]);
+            } else {
+                // three products: at most two key polys live at a time (the scheduler must not hoist the third load)
+                __builtin_amdgcn_sched_barrier(0);
+                cplx k2v[8];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) k2v[k2] = k_b[k2 * 64];
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) pa[k2] = cfma(x[k2], k1[k2], pa[k2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) pb[k2] = cfma(x[k2], k2v[k2], pb[k2]);
+            }
+        }
+        // hand the partial sums over
+        if (ROLE != MK3_PARTY) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) to_party[k2 * 64 + lane] = pa[k2];
+        }
+        if (ROLE != MK3_BODY) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) to_body[k2 * 64 + lane] = pb[k2];
+        }
+        __syncthreads();
+        if (ROLE == MK3_PARTY) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], cadd(xfer[0 * kM + k2 * 64 + lane], xfer[1 * kM + k2 * 64 + lane]));
+        } else if (ROLE == MK3_BODY) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], cadd(xfer[2 * kM + k2 * 64 + lane], xfer[3 * kM + k2 * 64 + lane]));
+        }
+        __syncthreads();      // the slots are free again (everything below is private to the wave)
+        fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
+        int32_t accr[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
+        untwist_add2<MARGIN>(own, accr, &worst);
+        store_acc<2>(lane, accr, acc_lds);
+        WAVE_LDS_FENCE();
+    }
+}
+
+template <int L, bool MARGIN = false>
+__global__ __launch_bounds__(192, 2) void mk_blind_rotate_kernel_w3(MkBrArgs P)
+{
+    constexpr int NP = 2;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [NP+1][N]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [3 waves][kXchElems]
+    cplx *xfer = xch_all + 3 * kXchElems;                                        // [4 slots][512]
+    cplx *tw2_lds = xfer + 4 * kM;                                               // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = tid >> 6;                                                     // wave = owned polynomial (0, 1: masks; 2: body)
+    int32_t *acc_lds = acc_all + wv * kN;
+    cplx *xch = xch_all + wv * kXchElems;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (NP * P.n + 1);
+    const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
+    {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
+        const int barb = bara[NP * P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            const int32_t body = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+            acc_lds[lane + 64 * m] = wv == NP ? body : 0;
+        }
+    }
+    __syncthreads();
+    // party-major double loop (mk_internals.jl:475-476); the wave's role changes with the party
+#pragma unroll 1
+    for (int party = 0; party < NP; party++) {
+        if (wv == NP) mk3_party_steps<L, MK3_BODY, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
+        else if (wv == party) mk3_party_steps<L, MK3_PARTY, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
+        else mk3_party_steps<L, MK3_OTHER, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
+    }
+    __syncthreads();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
+    int32_t *ext = P.ext + w * (NP * kN + 1);
+    if (wv < NP) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[jj];
+            if (jj == 0) ext[wv * kN] = v;
+            else ext[wv * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    } else if (lane == 0) {
+        ext[NP * kN] = acc_lds[0];
+    }
+}
+
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
 // Same algorithm as mk_blind_rotate_kernel with run-time P and L.  Only three spectrum accumulators are ever
 // live whatever P is: in step (party i, bit j) the new mask a'_s of a non-party s receives products of its OWN

@@ -103,6 +103,7 @@ struct tfhe_ctx {
     DevBuf bara, ext, map, io[4], diag, abar;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
+    int mk_variant = 3;            // 2-party kernel: 3 = three waves per rotation (default), 1 = one wave per rotation
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
@@ -627,7 +628,13 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
 // `s` wait for that event orders the two without blocking the host and without keeping the caller's stream handle.
 static int32_t enter_stream(tfhe_ctx *c, hipStream_t s)
 {
-    if (c->done_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->done_ev, 0));
+    if (!c->done_pending) return TFHE_OK;
+    // Already finished (the common case for callers that synchronise between calls): nothing to order, and the event is not
+    // handed to the runtime again — the stream it was recorded on may have been destroyed by its owner since.
+    const hipError_t q = hipEventQuery(c->done_ev);
+    if (q == hipSuccess) { c->done_pending = false; return TFHE_OK; }
+    if (q != hipErrorNotReady) return c->set_err(TFHE_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(q));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->done_ev, 0));
     return TFHE_OK;
 }
 static int32_t leave_stream(tfhe_ctx *c, hipStream_t s)
@@ -1147,7 +1154,27 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     a.n = n; a.mu = (int32_t)(1u << 29);
     const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
-    if (special) {
+    if (special && c->mk_variant == 3) {
+        // three waves per rotation: acc[3][N] | xch[3] | hand-off slots [4][M] | tw2
+        const size_t lds3 = (size_t)(NP + 1) * kN * 4 + (3 * kXchElems + 4 * kM + 64) * sizeof(cplx);
+#define LAUNCH_MK3(LL)                                                                                             \
+        do {                                                                                                       \
+            if (dg) {                                                                                              \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w3<LL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+                hipLaunchKernelGGL((mk_blind_rotate_kernel_w3<LL, true>), dim3((unsigned)B), dim3(192), lds3, s, a);  \
+            } else {                                                                                               \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w3<LL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+                hipLaunchKernelGGL((mk_blind_rotate_kernel_w3<LL, false>), dim3((unsigned)B), dim3(192), lds3, s, a); \
+            }                                                                                                      \
+        } while (0)
+        switch (c->P.bs_l) {
+        case 2: LAUNCH_MK3(2); break;
+        case 3: LAUNCH_MK3(3); break;
+        default: LAUNCH_MK3(4); break;
+        }
+#undef LAUNCH_MK3
+        name_kernel(c, "mk_blind_rotate_kernel_w3<%d>", c->P.bs_l);
+    } else if (special) {
 #define LAUNCH_MK(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, true>), dim3((unsigned)B), dim3(64), lds, s, a);   \
         else hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, false>), dim3((unsigned)B), dim3(64), lds, s, a)
@@ -1348,6 +1375,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "mk_variant")) {
+        if (value != 1 && value != 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_variant must be 1 (one wave per rotation) or 3 (three waves)");
+        c->mk_variant = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "ks_variant")) {
         if (value != 1 && value != 3 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_variant must be 1, 3 or 4");
         // only the selected family's key layout is kept on the device: choose before loading the keyswitch key

@@ -1,0 +1,30 @@
+#!/bin/bash
+# One GPU-box session: tests, bench line, other configs, profiles.  Usage: bash tools/gpu_session.sh <tag> [steps...]
+# steps (default all): test bench configs prof2 prof4a prof4b prof5
+# Every step runs under its own `timeout -k 10`; a step that times out or is killed ends the session (no further GPU step).
+TAG=${1:-run}; shift
+STEPS=${@:-test bench configs prof2 prof4a prof4b prof5}
+mkdir -p gpurun_out
+run() {  # run <seconds> <name> <command...>
+  local secs=$1 name=$2; shift 2
+  echo "== $name: $(date +%T)"
+  timeout -k 10 $secs "$@"
+  local rc=$?
+  echo "== $name rc=$rc $(date +%T)"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name timed out / was killed: stopping the session"; exit $rc; fi
+  return $rc
+}
+for s in $STEPS; do
+  case $s in
+    test)    run 900 pytest bash -c "python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1"; tail -30 gpurun_out/${TAG}_pytest.log ;;
+    testall) run 1000 pytest bash -c "python -m pytest tests -m gpu -q --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1"; tail -40 gpurun_out/${TAG}_pytest.log ;;
+    bench)   run 400 bench bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err"; cat gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
+    configs) for c in 1 2host 3 4a 4b 5 k2; do run 300 config_$c bash -c "python tools/run_config.py --config $c >> gpurun_out/${TAG}_configs.jsonl 2>> gpurun_out/${TAG}_configs.err"; done; cat gpurun_out/${TAG}_configs.jsonl ;;
+    prof2)   run 600 prof2 bash tools/profile.sh ${TAG}_cfg2 > gpurun_out/${TAG}_prof2.log 2>&1; tail -25 gpurun_out/${TAG}_prof2.log ;;
+    prof4a)  run 600 prof4a bash tools/profile.sh ${TAG}_cfg4a tools/run_config.py --config 4a > gpurun_out/${TAG}_prof4a.log 2>&1; tail -12 gpurun_out/${TAG}_prof4a.log ;;
+    prof4b)  run 600 prof4b bash tools/profile.sh ${TAG}_cfg4b tools/run_config.py --config 4b > gpurun_out/${TAG}_prof4b.log 2>&1; tail -12 gpurun_out/${TAG}_prof4b.log ;;
+    prof5)   run 600 prof5 bash tools/profile.sh ${TAG}_cfg5 tools/run_config.py --config 5 > gpurun_out/${TAG}_prof5.log 2>&1; tail -12 gpurun_out/${TAG}_prof5.log ;;
+    *) run 600 custom bash -c "$s" ;;
+  esac
+done
+echo "session done"
