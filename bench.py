@@ -353,10 +353,12 @@ def profile_counters(kernel_name, units_per_launch):
         except Exception:
             continue
         meta = d.get("_meta", {})
-        if meta.get("units_per_launch") not in (None, units_per_launch) or "bench.py" not in meta.get("command", "bench.py"):
+        if "bench.py" not in meta.get("command", "bench.py"):
             continue
         for k, v in d.items():
-            if k != "_meta" and re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(" ", "")):
+            if k == "_meta" or v.get("workgroups_per_launch") not in (None, units_per_launch):
+                continue
+            if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(" ", "")):
                 best = dict(v)
                 best["source"] = os.path.relpath(f, ROOT) + (f" ({meta.get('date')})" if meta.get("date") else "")
     return best

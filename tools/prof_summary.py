@@ -48,7 +48,6 @@ for f in find("pmc_*/**/*counter_collection.csv"):
             print("  {:<60s} {:<28s} avg={:.6g} (n={})".format(k[:60], c, s / n, n))
 
 counters = {"_meta": {"command": cmd, "date": time.strftime("%Y-%m-%d"), "correction": "FETCH_SIZE x2 (gfx950 wide-load undercount), every --pmc group in its own run"}}
-units = None
 for k, c in pmc.items():
     if not ("blind_rotate" in k or "keyswitch" in k):
         continue
@@ -69,9 +68,8 @@ for k, c in pmc.items():
         e["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         e["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-    if "blind_rotate" in k and k in grid: units = grid[k]
+    if k in grid: e["workgroups_per_launch"] = grid[k]      # blind-rotate kernels: one workgroup per rotation
     counters[k] = e
-counters["_meta"]["units_per_launch"] = units
 json.dump(counters, open(os.path.join(out, "counters.json"), "w"), indent=1)
 print("== derived (counters.json) ==")
 for k, e in counters.items():
