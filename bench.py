@@ -358,7 +358,7 @@ def profile_counters(kernel_name, units_per_launch):
         for k, v in d.items():
             if k == "_meta" or v.get("workgroups_per_launch") not in (None, units_per_launch):
                 continue
-            if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(" ", "")):
+            if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(", ", ",")):
                 best = dict(v)
                 best["source"] = os.path.relpath(f, ROOT) + (f" ({meta.get('date')})" if meta.get("date") else "")
     return best
