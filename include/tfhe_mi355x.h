@@ -184,6 +184,10 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *ctx, const int32_t *in, int32_t *out, int
 
 /* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file); 2 <= P <= 8, P <= the context's `parties`. */
 int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk, int32_t parties);
+/* The same key in the form the reference stores it (MKBootstrapKey.key[j, i] :: MKTransformedTGswExpSample,
+ * mk_internals.jl:274-288,442-461): complex128 [P][n][2*l*P + 2*l][N/2] spectra of polynomials.jl:106-112.  Loading
+ * is a permutation into the engine's order plus the 1/M scaling: nothing is re-transformed or rounded. */
+int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra, int32_t parties);
 /* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]. */
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks, int32_t parties);
 /* out[g] = mk_gate_nand(ck, in0[g], in1[g]); all host int32 [B][P*n+1]. */

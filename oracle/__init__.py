@@ -137,6 +137,26 @@ class Oracle:
                                     C.c_int64(npolys))
         assert rc == 0
 
+    def load_bootstrap_spectra(self, spectra):
+        """The key in the reference's stored form (complex128 [..., N/2], bootstrap.jl:12-14 / mk_internals.jl:442-461),
+        e.g. from a fixture minted by julia/mint_fixtures.jl: the FFT back-end then multiplies with exactly the
+        reference's spectra; the Int32 form (for the exact back-end) is their inverse transform (polynomials.jl:119-132)."""
+        sp = np.ascontiguousarray(spectra, dtype=np.complex128)
+        M = self.N // 2
+        assert sp.shape[-1] == M
+        flat = sp.reshape(-1, M)
+        self.bk_re = np.ascontiguousarray(flat.real).reshape(-1)
+        self.bk_im = np.ascontiguousarray(flat.imag).reshape(-1)
+        out = np.zeros((flat.shape[0], self.N), np.int32)
+        worst = 0.0
+        for q in range(flat.shape[0]):
+            re, im = np.ascontiguousarray(flat[q].real), np.ascontiguousarray(flat[q].imag)
+            m = C.c_double(0)
+            assert lib().orc_inverse_transform(_p(re), _p(im), C.c_int32(self.N), _p(out[q]), C.byref(m)) == 0
+            worst = max(worst, m.value)
+        assert worst < 0.25, f"spectra are not those of integer polynomials (margin {worst})"
+        self.bk_i32 = out.reshape(sp.shape[:-1] + (self.N,))
+
     def load_keyswitch_key(self, ks):
         self.ks = _i32(ks)
 

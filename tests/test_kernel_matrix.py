@@ -125,14 +125,14 @@ def _mk_check(eng, o, x, y, expect_kernel):
 
 @pytest.mark.parametrize("l", [2, 3, 4])
 def test_mk_two_party_kernel_every_l(tfhe, orc, l):
-    """mk_blind_rotate_kernel_w3<l> (three waves per rotation, the default) and mk_blind_rotate_kernel<l> (one wave):
-    2 parties; l = 4, beta = 7 is mktfhe_parameters_2party, mk_api.jl:4-10."""
+    """mk_blind_rotate_kernel_w2<l> (two waves per rotation, the default at l = 4) and mk_blind_rotate_kernel<l> (one
+    wave): 2 parties; l = 4, beta = 7 is mktfhe_parameters_2party, mk_api.jl:4-10."""
     p, rng, sks, ck, o = _mk(tfhe, orc, 2, l, 7, 12, 2, 60 + l)
     eng = ck.engine(0)
     x, y = _words(rng, 5, 2 * 12 + 1), _words(rng, 5, 2 * 12 + 1)[::-1].copy()
     x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
     y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
-    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_w3<{l}>")
+    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_w2<{l}>" if l == 4 else f"mk_blind_rotate_kernel<{l}>")
     eng.set_option("mk_variant", 1)
     _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel<{l}>")
     ck.close()
@@ -203,7 +203,7 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
 
 
 def test_config5_mk_two_party_1024(tfhe, orc):
-    """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel_w3<4>.
+    """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel_w2<4>.
     64 sampled rows equal the oracle word for word (decrypt-level MK checks are ~0.2 %/gate noisy by design of the
     scheme's parameters, SURVEY §4: at least 98.5 % must decrypt to NAND)."""
     p = tfhe.mktfhe_parameters_2party
@@ -219,7 +219,7 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     m1, m2 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     x, y = tfhe.mk_encrypt(rng, sks, m1), tfhe.mk_encrypt(rng, sks, m2)
     got = eng.mk_gate_nand(x, y)
-    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w3<4>"
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w2<4>"
     assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.985
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
@@ -230,7 +230,7 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     assert np.array_equal(again, got[:128]) and 0.0 < margin < 0.25, margin
     eng.set_option("mk_variant", 1)                 # the one-wave-per-rotation kernel gives the same words
     assert np.array_equal(eng.mk_gate_nand(x[:96], y[:96]), got[:96]) and eng.last_kernel_name() == "mk_blind_rotate_kernel<4>"
-    eng.set_option("mk_variant", 3)
+    eng.set_option("mk_variant", 2)
     # the fan-out context (two device contexts on this one GPU) gives the same words
     e2 = ck.engine([0, 0])
     assert e2.device_count() == 2

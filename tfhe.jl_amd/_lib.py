@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "tfhe_mk_gate_nand_batch", "tfhe_last_timing_ms", "tfhe_last_rotation_count", "tfhe_set_option",
     "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
-    "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz",
+    "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
 ]
 ABI_VERSION = 2
 
@@ -69,6 +69,7 @@ def load():
     lib.tfhe_keyswitch_batch.argtypes = [vp, vp, vp, i64]
     lib.tfhe_mk_load_bootstrap_key_i32.argtypes = [vp, vp, i32]
     lib.tfhe_mk_load_keyswitch_key.argtypes = [vp, vp, i32]
+    lib.tfhe_mk_load_bootstrap_key_c128.argtypes = [vp, vp, i32]
     lib.tfhe_mk_gate_nand_batch.argtypes = [vp, vp, vp, vp, i64]
     lib.tfhe_last_timing_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     lib.tfhe_last_rotation_count.argtypes = [vp]
@@ -252,6 +253,16 @@ class Engine:
         if bk.size != want:
             raise ValueError(f"multi-key bootstrap key has {bk.size} words, expected {want} for {P} parties")
         self._check(self._lib.tfhe_mk_load_bootstrap_key_i32(self._h, _ptr(bk), P))
+        self._mk_parties = P
+
+    def mk_load_bootstrap_key_spectra(self, spectra, parties):
+        """The reference's stored form: complex128 [P][n][2lP + 2l][N/2]."""
+        sp = np.ascontiguousarray(spectra, dtype=np.complex128)
+        P, l = int(parties), self.params.bs_decomp_length
+        want = P * self.n * (2 * l * P + 2 * l) * (self.N // 2)
+        if sp.size != want:
+            raise ValueError(f"multi-key bootstrap spectra have {sp.size} values, expected {want} for {P} parties")
+        self._check(self._lib.tfhe_mk_load_bootstrap_key_c128(self._h, _ptr(sp), P))
         self._mk_parties = P
 
     def mk_load_keyswitch_key(self, ks, parties):

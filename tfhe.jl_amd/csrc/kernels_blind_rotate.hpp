@@ -18,7 +18,21 @@ using namespace tfhe;
 struct DiagArgs {
     unsigned long long *margin_bits;
     unsigned long long *clk;
+    unsigned long long *phase;   // TFHE_STAMP builds only: [4 waves][16] shader-clock ticks per phase of workgroup 0
 };
+
+// Development aid (make stamp -> lib/libtfhe_mi355x_stamp.so, tools/phase_profile.py): with -DTFHE_STAMP the DIAG
+// instantiations of the multi-wave kernels also add up, per wave of workgroup 0, the shader-clock ticks between
+// consecutive STAMP(k) marks.  Compiled out of the shipped library.
+#ifdef TFHE_STAMP
+#define STAMP_DECL unsigned long long st_prev_ = __builtin_amdgcn_s_memtime(), st_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k) do { if (MARGIN) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += t_ - st_prev_; st_prev_ = t_; } } while (0)
+#define STAMP_FLUSH(diag, wave) do { if (MARGIN && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (diag).phase) { for (int k_ = 0; k_ < 16; k_++) (diag).phase[(wave) * 16 + k_] = st_acc_[k_]; } } while (0)
+#else
+#define STAMP_DECL do { } while (0)
+#define STAMP(k) do { } while (0)
+#define STAMP_FLUSH(diag, wave) do { } while (0)
+#endif
 
 template <bool DIAG>
 __device__ __forceinline__ void diag_begin(unsigned long long &t0, unsigned long long &r0)
@@ -29,7 +43,7 @@ __device__ __forceinline__ void diag_begin(unsigned long long &t0, unsigned long
     }
 }
 template <bool DIAG>
-__device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double worst, unsigned long long t0, unsigned long long r0)
+__device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double worst, unsigned long long t0, unsigned long long r0, bool clock_writer = (threadIdx.x == 0))
 {
     if constexpr (DIAG) {
 #pragma unroll
@@ -39,7 +53,7 @@ __device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double wor
         }
         if ((threadIdx.x & 63) == 0) {
             atomicMax(&d.margin_bits[w], (unsigned long long)__double_as_longlong(worst));
-            if (threadIdx.x == 0) {
+            if (clock_writer) {
                 d.clk[2 * w] = __builtin_amdgcn_s_memtime() - t0;
                 d.clk[2 * w + 1] = __builtin_amdgcn_s_memrealtime() - r0;
             }
@@ -522,143 +536,140 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
-// ---- multi-key blind rotation, 2 parties, THREE waves per rotation ---------------------------------------------
-// BASELINE config 5 is 1024 rotations: with one wave per rotation that is one wave per SIMD, each running 12 forward
-// and 3 inverse transforms per step back to back (a lone wave issues FP64 at half the SIMD's rate).  Here wave s
-// (s = 0, 1: party masks a_0, a_1; s = 2: body b) owns accumulator polynomial s: it rotates and decomposes only its own
-// polynomial, runs its L forward transforms and multiplies them into (mk_internals.jl:371-385)
-//     its OWN new polynomial          party wave: y[p, party]        other mask: y[p, party]        body: c0[p]
-//     the party's new mask (partial)                                  other mask: y[p, s]            body: c1[p]
-//     the new body (partial)          party wave: x[p, party]        other mask: x[p, s]
-// then the partial sums for the party's mask and for the body are handed over through LDS (two barriers per step), the
-// two owners add what they receive, and every wave inverse-transforms and updates its own polynomial.  Same words as
-// mk_blind_rotate_kernel; 4 (+1) transforms per wave and step instead of 15.
-enum { MK3_PARTY = 0, MK3_OTHER = 1, MK3_BODY = 2 };
-
-template <int L, int ROLE, bool MARGIN>
-__device__ __forceinline__ void mk3_party_steps(int lane, int party, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds /* own polynomial */,
-                                                cplx *xch, cplx *xfer, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
+// ---- multi-key blind rotation, 2 parties, TWO waves per rotation ------------------------------------------------
+// BASELINE config 5 is 1024 rotations: with one wave per rotation that is ONE wave per SIMD (a lone wave issues FP64 at
+// about half the SIMD's rate) running 12 forward and 3 inverse transforms per step back to back.  Here the two waves of
+// a workgroup split the decomposition digits: wave w transforms digits p in [w L/2, (w+1) L/2) of all three source
+// polynomials (a_0, a_1, b) and multiplies them into its own partial sums of the three new polynomials
+// (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
+// wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
+// polynomials.  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
+// reuses the transposition buffers).  Same words as mk_blind_rotate_kernel.  L must be even.
+template <int L, int PARTY, bool MARGIN>
+__device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
+                                                cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
+                                                int32_t xormask, double &worst)
 {
     constexpr int NP = 2;
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
+    constexpr int OTHER = 1 - PARTY;
     const int beta = P.g.log2_base;
-    const int s = ROLE == MK3_PARTY ? party : ROLE == MK3_OTHER ? 1 - party : NP;   // this wave's source polynomial
-    // hand-off slots (512 cplx each): 0 = body -> party, 1 = other -> party, 2 = party -> body, 3 = other -> body
-    cplx *to_party = xfer + (ROLE == MK3_BODY ? 0 : 1) * kM;
-    cplx *to_body = xfer + (ROLE == MK3_PARTY ? 2 : 3) * kM;
-    int a_next = bara[party * P.n] & (2 * kN - 1);
+    const int p0 = wv * (L / 2);                  // this wave's digits: p0 .. p0 + L/2 - 1
+    int a_next = bara[PARTY * P.n] & (2 * kN - 1);
+    STAMP_DECL;
 #pragma unroll 1
     for (int j = 0; j < P.n; j++) {
         const int a = a_next;
-        a_next = bara[party * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
-        const cplx *key = P.bk + ((size_t)party * P.n + j) * PER * kM + lane;
-        cplx own[8], pa[8], pb[8];                 // own polynomial; partial for the party's mask; partial for the body
+        a_next = bara[PARTY * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
+        const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
+        cplx out[NP + 1][8];                      // partial sums of the new a_0, a_1, b over this wave's digits
 #pragma unroll
-        for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); pa[q] = mk(0.0, 0.0); pb[q] = mk(0.0, 0.0); }
-        int32_t temp[16];
-        {
-            int32_t cur[16];
+        for (int d = 0; d <= NP; d++)
 #pragma unroll
-            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
-            int a_here = a;
-            asm volatile("" : "+v"(a_here));   // keeps the rotate addresses from being hoisted out of the step loop
-            rotate_sub2(lane, a_here, acc_lds, cur, P.g.offset, xormask, temp);
-        }
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
+            int32_t temp[16];
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
+            }
+            STAMP(0);
 #pragma unroll 1
-        for (int p = 0; p < L; p++) {
-            // key polys of this transform (mk_internals.jl:371-385), the first two requested before the FFT
-            const cplx *k_own, *k_a = nullptr, *k_b = nullptr;
-            if (ROLE == MK3_PARTY) {
-                k_own = key + (size_t)(L * NP + p * NP + s) * kM;            // y[p, party]  -> a'_party
-                k_b = key + (size_t)(p * NP + s) * kM;                       // x[p, party]  -> b'
-            } else if (ROLE == MK3_OTHER) {
-                k_own = key + (size_t)(L * NP + p * NP + party) * kM;        // y[p, party]  -> a'_s
-                k_a = key + (size_t)(L * NP + p * NP + s) * kM;              // y[p, s]      -> a'_party
-                k_b = key + (size_t)(p * NP + s) * kM;                       // x[p, s]      -> b'
-            } else {
-                k_own = key + (size_t)(2 * L * NP + p) * kM;                 // c0[p]        -> b'
-                k_a = key + (size_t)(2 * L * NP + L + p) * kM;               // c1[p]        -> a'_party
-            }
-            // (the wave with three products keeps one key poly in flight across the FFT, the others two)
-            cplx k0[8], k1[8];
+            for (int pp = 0; pp < L / 2; pp++) {
+                const int p = p0 + pp;
+                const cplx *k_party, *k_body, *k_other = nullptr;
+                if (s < NP) {
+                    k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
+                    k_body = key + (size_t)(p * NP + s) * kM;                   // x[p, s]      -> b'
+                    if (s != PARTY) k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;   // y[p, party] -> a'_s
+                } else {
+                    k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
+                    k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
+                }
+                cplx kpa[8];                      // requested before the FFT (a second poly in flight spills)
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) k0[k2] = k_own[k2 * 64];
-            if (ROLE != MK3_OTHER) {
+                for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_party[k2 * 64];
+                cplx x[8];
+                load_digits2(temp, p + 1, beta, x);
+                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch_own);
+                STAMP(1);
+                cplx kbo[8];
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) k1[k2] = (ROLE == MK3_PARTY ? k_b : k_a)[k2 * 64];
-            }
-            cplx x[8];
-            load_digits2(temp, p + 1, beta, x);
-            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
-            if (ROLE == MK3_OTHER) {
+                for (int k2 = 0; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) k1[k2] = k_a[k2 * 64];
-            }
+                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kpa[k2], out[PARTY][k2]);
+                if (s == OTHER) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) own[k2] = cfma(x[k2], k0[k2], own[k2]);
-            if (ROLE == MK3_PARTY) {
+                    for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_other[k2 * 64];
+                }
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) pb[k2] = cfma(x[k2], k1[k2], pb[k2]);
-            } else if (ROLE == MK3_BODY) {
+                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kbo[k2], out[NP][k2]);
+                if (s == OTHER) {
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) pa[k2] = cfma(x[k2], k1[k2], pa[k2]);
-            } else {
-                // three products: at most two key polys live at a time (the scheduler must not hoist the third load)
-                __builtin_amdgcn_sched_barrier(0);
-                cplx k2v[8];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) k2v[k2] = k_b[k2 * 64];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) pa[k2] = cfma(x[k2], k1[k2], pa[k2]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) pb[k2] = cfma(x[k2], k2v[k2], pb[k2]);
+                    for (int k2 = 0; k2 < 8; k2++) out[OTHER][k2] = cfma(x[k2], kpa[k2], out[OTHER][k2]);
+                }
+                STAMP(2);
             }
         }
-        // hand the partial sums over
-        if (ROLE != MK3_PARTY) {
+        // hand-off: each wave writes what the other one owns into its OWN transposition buffer (+ the extra slot), so
+        // nothing of the other wave's is touched before the barrier
+        if (wv == 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) to_party[k2 * 64 + lane] = pa[k2];
-        }
-        if (ROLE != MK3_BODY) {
+            for (int k2 = 0; k2 < 8; k2++) xch_own[k2 * 64 + lane] = out[NP][k2];
+        } else {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) to_body[k2 * 64 + lane] = pb[k2];
+            for (int k2 = 0; k2 < 8; k2++) { xch_own[k2 * 64 + lane] = out[0][k2]; extra[k2 * 64 + lane] = out[1][k2]; }
         }
+        STAMP(3);
         __syncthreads();
-        if (ROLE == MK3_PARTY) {
+        STAMP(4);
+        if (wv == 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], cadd(xfer[0 * kM + k2 * 64 + lane], xfer[1 * kM + k2 * 64 + lane]));
-        } else if (ROLE == MK3_BODY) {
+            for (int k2 = 0; k2 < 8; k2++) { out[0][k2] = cadd(out[0][k2], xch_oth[k2 * 64 + lane]); out[1][k2] = cadd(out[1][k2], extra[k2 * 64 + lane]); }
+        } else {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], cadd(xfer[2 * kM + k2 * 64 + lane], xfer[3 * kM + k2 * 64 + lane]));
+            for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cadd(out[NP][k2], xch_oth[k2 * 64 + lane]);
         }
-        __syncthreads();      // the slots are free again (everything below is private to the wave)
-        fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
-        int32_t accr[16];
+        STAMP(5);
+        __syncthreads();      // both have read: the transposition buffers are their owners' again
+        STAMP(6);
+        auto finish = [&](cplx (&o)[8], int d) {
+            fft_inv_wave(lane, o, tw1f, tw2_lds, xch_own);
+            int32_t accr[16];
 #pragma unroll
-        for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
-        untwist_add2<MARGIN>(own, accr, &worst);
-        store_acc<2>(lane, accr, acc_lds);
-        WAVE_LDS_FENCE();
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2<MARGIN>(o, accr, &worst);
+            store_acc<2>(lane, accr, acc_lds + d * kN);
+        };
+        if (wv == 0) { finish(out[0], 0); finish(out[1], 1); }
+        else finish(out[NP], NP);
+        STAMP(7);
+        __syncthreads();      // the updated accumulator is visible to both waves' rotations of the next step
+        STAMP(8);
     }
+    if (PARTY == 1) STAMP_FLUSH(P.diag, wv);
 }
 
 template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(192, 2) void mk_blind_rotate_kernel_w3(MkBrArgs P)
+__global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
 {
+    static_assert(L % 2 == 0, "the two waves split the digits evenly");
     constexpr int NP = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [NP+1][N]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [3 waves][kXchElems]
-    cplx *xfer = xch_all + 3 * kXchElems;                                        // [4 slots][512]
-    cplx *tw2_lds = xfer + 4 * kM;                                               // [8][8]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = tid >> 6;                                                     // wave = owned polynomial (0, 1: masks; 2: body)
-    int32_t *acc_lds = acc_all + wv * kN;
-    cplx *xch = xch_all + wv * kXchElems;
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                        // [NP+1][N]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [2 waves][kXchElems]
+    cplx *extra = xch_all + 2 * kXchElems;                                       // [512] second hand-off slot of wave 1
+    cplx *tw2_lds = extra + kM;                                                  // [8][8]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    cplx *xch_own = xch_all + wv * kXchElems, *xch_oth = xch_all + (1 - wv) * kXchElems;
     const size_t w = blockIdx.x;
     const int32_t *bara = P.bara + w * (NP * P.n + 1);
     const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
@@ -669,36 +680,27 @@ __global__ __launch_bounds__(192, 2) void mk_blind_rotate_kernel_w3(MkBrArgs P)
     if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
     {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
         const int barb = bara[NP * P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            const int32_t body = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-            acc_lds[lane + 64 * m] = wv == NP ? body : 0;
+        for (int j = tid; j < kN; j += 128) {
+            const int idx = (j + barb) & (2 * kN - 1);
+            acc_lds[j] = 0;
+            acc_lds[kN + j] = 0;
+            acc_lds[2 * kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
         }
     }
     __syncthreads();
-    // party-major double loop (mk_internals.jl:475-476); the wave's role changes with the party
-#pragma unroll 1
-    for (int party = 0; party < NP; party++) {
-        if (wv == NP) mk3_party_steps<L, MK3_BODY, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
-        else if (wv == party) mk3_party_steps<L, MK3_PARTY, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
-        else mk3_party_steps<L, MK3_OTHER, MARGIN>(lane, party, P, bara, acc_lds, xch, xfer, tw2_lds, tw1f, xormask, worst);
-    }
-    __syncthreads();
+    // party-major double loop (mk_internals.jl:475-476)
+    mk2_party_steps<L, 0, MARGIN>(lane, wv, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+    mk2_party_steps<L, 1, MARGIN>(lane, wv, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
-    if (wv < NP) {
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int jj = lane + 64 * m;
-            const int32_t v = acc_lds[jj];
-            if (jj == 0) ext[wv * kN] = v;
-            else ext[wv * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
-        }
-    } else if (lane == 0) {
-        ext[NP * kN] = acc_lds[0];
+    for (int jj = tid; jj < NP * kN; jj += 128) {
+        const int c = jj >> 10, j1 = jj & (kN - 1);
+        const int32_t v = acc_lds[jj];
+        if (j1 == 0) ext[c * kN] = v;
+        else ext[c * kN + kN - j1] = (int32_t)(0u - (uint32_t)v);
     }
+    if (tid == 0) ext[NP * kN] = acc_lds[NP * kN];
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
@@ -872,6 +874,7 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
         }
     }
     __syncthreads();
+    STAMP_DECL;
 
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
             for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
             rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
         }
+        STAMP(0);
 #pragma unroll 1
         for (int p = 0; p < L; p++) {
             cplx x[8];
@@ -897,6 +901,7 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) kown[k2] = kp[(size_t)wv * kM + k2 * 64];           // co = wv (issued before the FFT)
             fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            STAMP(1);
             cplx koth[8];
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) koth[k2] = kp[(size_t)(1 - wv) * kM + k2 * 64];     // co = 1 - wv
@@ -904,22 +909,29 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
             for (int k2 = 0; k2 < 8; k2++) own[k2] = cfma(x[k2], kown[k2], own[k2]);
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) oth[k2] = cfma(x[k2], koth[k2], oth[k2]);
+            STAMP(2);
         }
         // hand the other component's partial sum over (buffer by step parity: one barrier per step)
         cplx *mine = xfer + ((i & 1) * 2 + wv) * kM, *theirs = xfer + ((i & 1) * 2 + (1 - wv)) * kM;
 #pragma unroll
         for (int k2 = 0; k2 < 8; k2++) mine[k2 * 64 + lane] = oth[k2];
+        STAMP(3);
         __syncthreads();
+        STAMP(4);
 #pragma unroll
         for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], theirs[k2 * 64 + lane]);
+        STAMP(5);
         fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
+        STAMP(6);
         int32_t accr[16];
 #pragma unroll
         for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
         untwist_add2<MARGIN>(own, accr, &worst);
         store_acc<2>(lane, accr, acc_lds);
         WAVE_LDS_FENCE();
+        STAMP(7);
     }
+    STAMP_FLUSH(P.diag, wv);
     __syncthreads();
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN + 1);
@@ -1079,6 +1091,7 @@ struct Br2048Args {
     const cplx *tw2;       // [8][8]
     Gadget g;
     int32_t n, mu;
+    int32_t R;             // rotations in the batch (workgroups hold several: the last one may be padded)
 };
 
 // pass-A input from the four coefficient classes of point jj = t + 64 r (values already converted to double)
@@ -1112,22 +1125,29 @@ __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx 
     fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
 }
 
-template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P)
+// RW rotations per workgroup (2 waves each) advance in lockstep (the barriers are workgroup-wide): the transformed
+// key of N = 2048 sets (124 MB at n = 630, l = 3) does not stay in the 4 MB L2 of an XCD once workgroups drift apart,
+// and rotations that read the same key values at the same time share one trip to the Infinity Cache.
+template <int L, bool MARGIN = false, int RW = 2>
+__global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel_n2048(Br2048Args P)
 {
     constexpr int K1 = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                         // [K1][2048]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN2 * 4);                // [2 waves][kXchElems]
-    cplx *tw2_lds = xch_all + 2 * kXchElems;                                      // [8][8]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool wave1 = (tid >> 6) != 0;                                           // wave-uniform
+    const int tid = threadIdx.x, lane = tid & 63, tid_r = tid & 127;              // tid_r: thread within its rotation
+    const int rot = tid >> 7;                                                     // rotation within the workgroup
+    constexpr size_t kRotBytes = K1 * kN2 * 4 + 2 * kXchElems * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][2048]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kN2 * 4);   // [2 waves][kXchElems]
+    cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
+    const bool wave1 = ((tid >> 6) & 1) != 0;                                     // wave-uniform
     cplx *xch = xch_all + (wave1 ? kXchElems : 0);
     cplx *xch_other = xch_all + (wave1 ? 0 : kXchElems);
-    const size_t w = blockIdx.x;
+    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const bool live = w_raw < (size_t)P.R;                                        // a padding rotation repeats the last one, stores nothing
+    const size_t w = live ? w_raw : (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
@@ -1139,17 +1159,20 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
     if (tid < 64) tw2_lds[tid] = P.tw2[tid];
     {
         const int barb = bara[P.n] & (2 * kN2 - 1);
-        for (int j = tid; j < kN2; j += 128) {
+        for (int j = tid_r; j < kN2; j += 128) {
             const int idx = (j + barb) & (2 * kN2 - 1);
             acc_lds[j] = 0;
             acc_lds[kN2 + j] = (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
         }
     }
     __syncthreads();
+    STAMP_DECL;
 
+    int a_next = bara[0] & (2 * kN2 - 1);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
-        const int a = bara[i] & (2 * kN2 - 1);
+        const int a = a_next;
+        a_next = bara[i + 1] & (2 * kN2 - 1);   // bara[n] (= barb) exists: harmless read on the last step
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;
         cplx out[K1][8];
 #pragma unroll
@@ -1164,6 +1187,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
                 asm volatile("" : "+v"(a_here));
                 rotate_sub_2048(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
             }
+            STAMP(0);
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
                 cplx x[8];
@@ -1173,7 +1197,11 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
                     const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
                     x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
                 });
+                STAMP(1);
                 fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+                STAMP(2);
+                // (requesting the co = 0 chunk before the FFT, as the N = 1024 kernels do, costs 32 more live registers
+                //  here: with temp[32] live across the transform that spills into the loop and is slower, measured)
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
 #pragma unroll
                 for (int co = 0; co < K1; co++) {
@@ -1183,19 +1211,24 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
                 }
+                STAMP(3);
             }
         }
         __syncthreads();   // every rotated read of this step is done before anybody updates acc_lds
+        STAMP(4);
 #pragma unroll
         for (int d = 0; d < K1; d++) {
             fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);          // alpha (wave 0) / beta (wave 1)
+            STAMP(5);
 #pragma unroll
             for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[d][r];
             __syncthreads();
+            STAMP(6);
             cplx oth[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
             __syncthreads();
+            STAMP(7);
             // wave 0: (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024
             // wave 1: (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
             static_for<0, 8>([&](auto rc) {
@@ -1217,18 +1250,22 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_n2048(Br2048Args P
                 ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));
                 ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));
             });
+            STAMP(8);
         }
         __syncthreads();
+        STAMP(9);
     }
+    STAMP_FLUSH(P.diag, threadIdx.x >> 6);
 
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    if (!live) return;
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
     int32_t *ext = P.ext + w * (kN2 + 1);
-    for (int j = tid; j < kN2; j += 128) {
+    for (int j = tid_r; j < kN2; j += 128) {
         const int32_t v = acc_lds[j];
         if (j == 0) ext[0] = v;
         else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
     }
-    if (tid == 0) ext[kN2] = acc_lds[kN2];
+    if (tid_r == 0) ext[kN2] = acc_lds[kN2];
 }
 
 // key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024

@@ -103,7 +103,8 @@ struct tfhe_ctx {
     DevBuf bara, ext, map, io[4], diag, abar;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
-    int mk_variant = 3;            // 2-party kernel: 3 = three waves per rotation (default), 1 = one wave per rotation
+    int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
+    int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
@@ -469,13 +470,14 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 // ---- launch helpers ------------------------------------------------------------------------------
 static int32_t prepare_diag(tfhe_ctx *c, size_t R, hipStream_t s, DiagArgs &d)
 {
-    d.margin_bits = nullptr; d.clk = nullptr;
+    d.margin_bits = nullptr; d.clk = nullptr; d.phase = nullptr;
     c->diag_rows = 0;
     if (!c->measure_margin) return TFHE_OK;
-    HIP_TRY(c, c->diag.reserve(R * 24));
-    HIP_TRY(c, hipMemsetAsync(c->diag.p, 0, R * 24, s));
+    HIP_TRY(c, c->diag.reserve(R * 24 + 64 * 8));
+    HIP_TRY(c, hipMemsetAsync(c->diag.p, 0, R * 24 + 64 * 8, s));
     d.margin_bits = (unsigned long long *)c->diag.p;
     d.clk = d.margin_bits + R;
+    d.phase = d.clk + 2 * R;
     c->diag_rows = R;
     return TFHE_OK;
 }
@@ -516,14 +518,32 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     if (c->P.N == kN2) {
         Br2048Args b;
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu;
-        const size_t ldsb = 2 * kN2 * 4 + (2 * kXchElems + 64) * sizeof(cplx);
+        b.R = (int32_t)R;
+        // n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation per workgroup)
+        const int rw = c->n2048_rw;
+        const size_t ldsb = (size_t)rw * (2 * kN2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
+        const unsigned nblk = (unsigned)((R + rw - 1) / rw);
+#define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
+        do {                                                                                                       \
+            if (ldsb > 64 * 1024)                                                                                  \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_n2048<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+            hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b); \
+        } while (0)
 #define LAUNCH_2048(LL)                                                                                            \
-        if (dg) hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, true>), dim3((unsigned)R), dim3(128), ldsb, s, b); \
-        else hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, false>), dim3((unsigned)R), dim3(128), ldsb, s, b)
+        do {                                                                                                       \
+            if (rw == 4 && dg) LAUNCH_2048_RW(LL, true, 4);                                                        \
+            else if (rw == 4) LAUNCH_2048_RW(LL, false, 4);                                                        \
+            else if (rw == 2 && dg) LAUNCH_2048_RW(LL, true, 2);                                                   \
+            else if (rw == 2) LAUNCH_2048_RW(LL, false, 2);                                                        \
+            else if (dg) LAUNCH_2048_RW(LL, true, 1);                                                              \
+            else LAUNCH_2048_RW(LL, false, 1);                                                                     \
+        } while (0)
         BR_CASES(LAUNCH_2048)
+#undef LAUNCH_2048_RW
 #undef LAUNCH_2048
         HIP_TRY(c, hipGetLastError());
         name_kernel(c, "blind_rotate_kernel_n2048<%d>", L);
+        (void)nblk;
         return TFHE_OK;
     }
     if (c->P.k == 2) {
@@ -1028,23 +1048,25 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     return TFHE_OK;
 }
 
-int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t parties)
+static int32_t mk_load_bk_common(tfhe_ctx *c, const void *bk, int32_t parties, bool is_c128)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!bk) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: NULL key pointer");
     if (parties < 2 || parties > 8 || c->P.parties < parties)
         return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
-    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_mk_load_bootstrap_key_i32(c->kids[(size_t)k], bk, parties); });
+    if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return mk_load_bk_common(c->kids[(size_t)k], bk, parties, is_c128); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t per = (size_t)2 * c->P.bs_l * parties + 2 * c->P.bs_l;
     const size_t npolys = (size_t)parties * c->P.n * per;
+    const size_t bytes_in = is_c128 ? npolys * kM * sizeof(cplx) : npolys * kN * 4;
     if (c->d_mk_bk) { (void)hipFree(c->d_mk_bk); c->d_mk_bk = nullptr; c->have_mk_bk = false; }
     HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * kM * sizeof(cplx)));
     void *d_in = nullptr;
-    HIP_TRY(c, hipMalloc(&d_in, npolys * kN * 4));
-    hipError_t e = hipMemcpyAsync(d_in, bk, npolys * kN * 4, hipMemcpyHostToDevice, c->stream);
+    HIP_TRY(c, hipMalloc(&d_in, bytes_in));
+    hipError_t e = hipMemcpyAsync(d_in, bk, bytes_in, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T);
+        if (is_c128) hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_mk_bk);
+        else hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1054,6 +1076,10 @@ int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t p
     c->have_mk_bk = true;
     return TFHE_OK;
 }
+
+int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t parties) { return mk_load_bk_common(c, bk, parties, false); }
+
+int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra, int32_t parties) { return mk_load_bk_common(c, bk_spectra, parties, true); }
 
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parties)
 {
@@ -1154,26 +1180,15 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     a.n = n; a.mu = (int32_t)(1u << 29);
     const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
-    if (special && c->mk_variant == 3) {
-        // three waves per rotation: acc[3][N] | xch[3] | hand-off slots [4][M] | tw2
-        const size_t lds3 = (size_t)(NP + 1) * kN * 4 + (3 * kXchElems + 4 * kM + 64) * sizeof(cplx);
-#define LAUNCH_MK3(LL)                                                                                             \
-        do {                                                                                                       \
-            if (dg) {                                                                                              \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w3<LL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
-                hipLaunchKernelGGL((mk_blind_rotate_kernel_w3<LL, true>), dim3((unsigned)B), dim3(192), lds3, s, a);  \
-            } else {                                                                                               \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w3<LL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
-                hipLaunchKernelGGL((mk_blind_rotate_kernel_w3<LL, false>), dim3((unsigned)B), dim3(192), lds3, s, a); \
-            }                                                                                                      \
-        } while (0)
-        switch (c->P.bs_l) {
-        case 2: LAUNCH_MK3(2); break;
-        case 3: LAUNCH_MK3(3); break;
-        default: LAUNCH_MK3(4); break;
-        }
-#undef LAUNCH_MK3
-        name_kernel(c, "mk_blind_rotate_kernel_w3<%d>", c->P.bs_l);
+    if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
+        // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
+        const size_t lds2 = (size_t)(NP + 1) * kN * 4 + (2 * kXchElems + kM + 64) * sizeof(cplx);
+#define LAUNCH_MK2(LL)                                                                                             \
+        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, true>), dim3((unsigned)B), dim3(128), lds2, s, a); \
+        else hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, false>), dim3((unsigned)B), dim3(128), lds2, s, a)
+        LAUNCH_MK2(4);
+#undef LAUNCH_MK2
+        name_kernel(c, "mk_blind_rotate_kernel_w2<%d>", c->P.bs_l);
     } else if (special) {
 #define LAUNCH_MK(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, true>), dim3((unsigned)B), dim3(64), lds, s, a);   \
@@ -1351,6 +1366,18 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *c, double *mhz)
     return read_diag(c, nullptr, mhz);
 }
 
+#ifdef TFHE_STAMP
+// development builds only (make stamp): per-phase shader-clock ticks of workgroup 0's waves, [4 waves][16]
+int32_t tfhe_debug_phases(tfhe_ctx *c, unsigned long long *out64)
+{
+    if (!c || !out64 || c->multi() || !c->diag_rows) return TFHE_ERR_STATE;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(out64, (const char *)c->diag.p + c->diag_rows * 24, 64 * 8, hipMemcpyDeviceToHost));
+    return TFHE_OK;
+}
+#endif
+
 int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
@@ -1375,8 +1402,13 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "n2048_rw")) {
+        if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
+        c->n2048_rw = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "mk_variant")) {
-        if (value != 1 && value != 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_variant must be 1 (one wave per rotation) or 3 (three waves)");
+        if (value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_variant must be 1 (one wave per rotation) or 2 (two waves)");
         c->mk_variant = (int)value;
         return TFHE_OK;
     }

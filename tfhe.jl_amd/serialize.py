@@ -9,7 +9,7 @@ julia/TFHEMI355X.jl's flattening — can be replayed on a GPU box.  Layout (litt
                   | ndim u32 | shape u64[ndim] | raw C-order data
 
 Sections of a cloud key: "params" (int32[8] as tfhe_params + float64 noise fields in "noise"),
-"bootstrap_key" (int32 [n][l][k+1][k+1][N], or "bootstrap_spectra" complex128 [n][l][k+1][k+1][N/2]),
+"bootstrap_key" (int32 [n][l][k+1][k+1][N], or "bk_spectra" complex128 [n][l][k+1][k+1][N/2]),
 "keyswitch_key" (int32 [kN][t][base-1][n+1]).
 """
 import struct
@@ -82,7 +82,7 @@ class LoadedCloudKey:
         noise = sections.get("noise", np.zeros(3))
         self.params = SchemeParameters(n, float(noise[0]), N, k, l, b, float(noise[1]), t, g, float(noise[2]), parties)
         self.bootstrap_key = sections.get("bootstrap_key")
-        self.bootstrap_spectra = sections.get("bootstrap_spectra")
+        self.bootstrap_spectra = sections.get("bk_spectra")
         self.keyswitch_key = sections["keyswitch_key"]
         self._engines = {}
 

@@ -26,6 +26,14 @@ def br_bytes(p, parties=1):
     return p.lwe_size * p.bs_decomp_length * (p.tlwe_mask_size + 1) ** 2 * p.tlwe_polynomial_degree * 4
 
 
+OPTIONS = []
+
+
+def apply_options(eng):
+    for name, value in OPTIONS:
+        eng.set_option(name, value)
+
+
 def timed_calls(fn, reps):
     fn()
     wall = []
@@ -49,6 +57,7 @@ def single_key(params, B, reps, seed, want_diag, label):
     rng = np.random.default_rng(seed)
     sk, ck = tfhe.make_key_pair(rng, params)
     eng = ck.engine(0)
+    apply_options(eng)
     bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     x, y = tfhe.encrypt(rng, sk, bx).data, tfhe.encrypt(rng, sk, by).data
     ops = np.zeros(B, np.uint8)
@@ -58,7 +67,7 @@ def single_key(params, B, reps, seed, want_diag, label):
         eng.gates(ops, x, y); br.append(eng.last_timing_ms(0)); ks.append(eng.last_timing_ms(1))
     wall = timed_calls(call, reps)
     brm = float(np.median(br[1:]))
-    res = {"config": label, "gates": B, "kernel": eng.last_kernel_name(), "blind_rotate_ms": brm, "keyswitch_ms": float(np.median(ks[1:])),
+    res = {"config": label, "options": dict(OPTIONS), "gates": B, "kernel": eng.last_kernel_name(), "blind_rotate_ms": brm, "keyswitch_ms": float(np.median(ks[1:])),
            "host_wall_ms": wall * 1e3, "gates_per_s_host_buffers": B / wall, "rot_per_s": B / brm * 1e3,
            "bytes_per_rotation": br_bytes(params), "frac_hbm_algorithmic": B / brm * 1e3 * br_bytes(params) / HBM_PEAK,
            "decrypt_ok_fraction": float((tfhe.decrypt(sk, out) == ~(bx & by)).mean())}
@@ -74,7 +83,11 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--gates", type=int, default=0)
     ap.add_argument("--no-diag", action="store_true")
+    ap.add_argument("--lwe-size", type=int, default=0, help="experiment: override n (a shorter key that stays in L2 separates memory stalls from the rest)")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="engine option (tfhe_set_option) applied before the runs, e.g. --set n2048_rw=1")
     a = ap.parse_args()
+    global OPTIONS
+    OPTIONS = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.set]
     want_diag = not a.no_diag
     if a.config == "1":
         res = single_key(tfhe.tfhe_parameters_80(), 1, max(a.reps, 20), 123, want_diag, "1: single gate_nand, tfhe_parameters_80")
@@ -83,7 +96,7 @@ def main():
     elif a.config == "4a":
         res = single_key(tfhe.tfhe_parameters_128(), a.gates or 4096, a.reps, 123, want_diag, "4a: tfhe_parameters_128, 4096 NAND")
     elif a.config == "4b":
-        p = tfhe.SchemeParameters(630, 1 / 2**15, 2048, 1, 3, 7, 1 / 2**25, 8, 2, 1 / 2**15, 1)
+        p = tfhe.SchemeParameters(a.lwe_size or 630, 1 / 2**15, 2048, 1, 3, 7, 1 / 2**25, 8, 2, 1 / 2**15, 1)
         res = single_key(p, a.gates or 4096, a.reps, 2048, want_diag, "4b: synthetic N=2048 (n=630, l=3, beta=7), 4096 NAND")
     elif a.config == "k2":
         res = single_key(tfhe.tfhe_parameters_80(tlwe_mask_size=2), a.gates or 4096, a.reps, 77, want_diag, "tfhe_parameters_80(tlwe_mask_size=2), 4096 NAND")
@@ -103,6 +116,8 @@ def main():
         ck.close()
     else:   # 5: 2-party MK NAND
         p = tfhe.mktfhe_parameters_2party
+        if a.lwe_size:
+            p = tfhe.SchemeParameters(a.lwe_size, p.lwe_noise_stddev, 1024, 1, 4, 7, p.bs_noise_stddev, 8, 2, p.ks_noise_stddev, 2)
         mrng = np.random.default_rng(321)
         sks = [tfhe.SecretKey(mrng, p) for _ in range(2)]
         shared = tfhe.SharedKey(mrng, p)
@@ -111,13 +126,14 @@ def main():
         m1, m2 = mrng.integers(0, 2, B).astype(bool), mrng.integers(0, 2, B).astype(bool)
         xm, ym = tfhe.mk_encrypt(mrng, sks, m1), tfhe.mk_encrypt(mrng, sks, m2)
         em = mck.engine(0)
+        apply_options(em)
         out = em.mk_gate_nand(xm, ym)
         br, ks = [], []
         def call():
             em.mk_gate_nand(xm, ym); br.append(em.last_timing_ms(0)); ks.append(em.last_timing_ms(1))
         wall = timed_calls(call, a.reps)
         brm = float(np.median(br[1:]))
-        res = {"config": "5: 2-party MK NAND", "gates": B, "kernel": em.last_kernel_name(), "blind_rotate_ms": brm, "keyswitch_ms": float(np.median(ks[1:])),
+        res = {"config": "5: 2-party MK NAND", "options": dict(OPTIONS), "gates": B, "kernel": em.last_kernel_name(), "blind_rotate_ms": brm, "keyswitch_ms": float(np.median(ks[1:])),
                "host_wall_ms": wall * 1e3, "gates_per_s_host_buffers": B / wall, "rot_per_s": B / brm * 1e3, "bytes_per_rotation": br_bytes(p, 2),
                "frac_hbm_algorithmic": B / brm * 1e3 * br_bytes(p, 2) / HBM_PEAK,
                "decrypt_ok_fraction": float((tfhe.mk_decrypt(sks, out) == ~(m1 & m2)).mean())}
