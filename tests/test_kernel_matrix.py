@@ -52,6 +52,7 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     K = _setup(tfhe, orc, 1024, 1, l, BETA_1024[l])
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(l), 6, K.params.lwe_size + 1)
+    _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")        # the default for a batch this small
     eng.set_option("br_small", -1)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},16>", f"v3<{l},16>")
     eng.set_option("br_variant", 3)
@@ -67,10 +68,13 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     # the switch between the two kernels is by batch size: 513 rotations take v3<l,16> without any option
     big = np.repeat(x[2:3], 513, axis=0)
     big[:, 0] += np.arange(513, dtype=np.int32) << 21        # distinct first exponents
-    got = eng.bootstrap(MU, big, with_keyswitch=False)
-    assert eng.last_kernel_name() == f"blind_rotate_kernel_v3<{l},16>"
-    idx = [0, 1, 255, 511, 512]
-    assert np.array_equal(got[idx], K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=5))
+    idx = [0, 1, 255, 256, 511, 512]
+    want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=6)
+    for rows, kernel in ((512, f"blind_rotate_kernel_w2<{l}>"), (513, f"blind_rotate_kernel_v3<{l},16>")):
+        got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
+        assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
+        sel = [j for j, r in enumerate(idx) if r < rows]
+        assert np.array_equal(got[[idx[j] for j in sel]], want[sel]), rows
     K.ck.close()
 
 

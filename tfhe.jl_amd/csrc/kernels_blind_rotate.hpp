@@ -839,6 +839,9 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
 // the partial sum for the other component over through LDS (double-buffered, ONE barrier per step), adds
 // what it receives, inverse-transforms its own component and updates its own polynomial.  Same arithmetic
 // per rotation as blind_rotate_kernel_v3, about half the latency.
+// (Measured dead end: one wave per (component, digit) — 2 l waves, one forward transform each — is no faster, 1.94 vs
+//  1.89 ms per gate: a lone wave issues FP64 at about half the SIMD's rate, and four waves transposing at once run into
+//  the CU's LDS store bandwidth, so every transform gets slower as the step gets shorter.)
 template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
 {
@@ -876,9 +879,11 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
     __syncthreads();
     STAMP_DECL;
 
+    int a_next = bara[0] & (2 * kN - 1);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
-        const int a = bara[i] & (2 * kN - 1);
+        const int a = a_next;
+        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         // key polys of transform (p, c = wv): [i][p][c][co][8][64]
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
         cplx own[8], oth[8];
