@@ -188,6 +188,15 @@ int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk, int32_t
  * mk_internals.jl:274-288,442-461): complex128 [P][n][2*l*P + 2*l][N/2] spectra of polynomials.jl:106-112.  Loading
  * is a permutation into the engine's order plus the 1/M scaling: nothing is re-transformed or rounded. */
 int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra, int32_t parties);
+/* MKBootstrapKey built ON THE DEVICE from what the parties publish: RGSW.Expand (mk_tgsw_expand, mk_internals.jl:304-345)
+ * of every party's uni-encrypted key bits against all public keys, then the forward transform (MKBootstrapKey,
+ * :442-461).  pub_b: Int32 [P][l][N] (PublicKey.b, :116-139); c0, c1, d0, d1, f0, f1: Int32 [P][n][l][N]
+ * (MKTGswUESample of bit j of party i, :185-227).  The host only decomposes the public-key differences; the
+ * P (P-1) n l^2 polynomial products run on the GPU (exact, like the external product).  If expanded_out is not NULL it
+ * receives the expanded key in the Int32 layout tfhe_mk_load_bootstrap_key_i32 takes ([P][n][2 l P + 2 l][N]). */
+int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *ctx, int32_t parties, const int32_t *pub_b, const int32_t *c0,
+                                          const int32_t *c1, const int32_t *d0, const int32_t *d1, const int32_t *f0,
+                                          const int32_t *f1, int32_t *expanded_out);
 /* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]. */
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks, int32_t parties);
 /* out[g] = mk_gate_nand(ck, in0[g], in1[g]); all host int32 [B][P*n+1]. */

@@ -126,3 +126,28 @@ def test_mk_gpu_parity_many_parties(orc, tfhe, which, parties, n):
     if parties == 2:
         assert np.array_equal(got, special)
     ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,parties,n", [("2party", 2, 12), ("4party", 4, 8), ("4party", 3, 8), ("8party", 8, 4)])
+def test_device_rgsw_expand_equals_host(orc, tfhe, which, parties, n):
+    """RGSW.Expand on the GPU (tfhe_mk_expand_load_bootstrap_key; mk_internals.jl:304-345): the expanded Int32 key equals
+    the host expansion word for word, and the engine it leaves loaded computes the same NAND words as the oracle."""
+    base = getattr(tfhe, "mktfhe_parameters_" + which)
+    p = tfhe.SchemeParameters(n, base.lwe_noise_stddev, 1024, 1, base.bs_decomp_length, base.bs_log2_base, base.bs_noise_stddev,
+                              base.ks_decomp_length, base.ks_log2_base, base.ks_noise_stddev, base.max_parties)
+    rng = np.random.default_rng(900 + parties)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
+    shared = tfhe.SharedKey(rng, p)
+    parts = [tfhe.CloudKeyPart(rng, sk, shared) for sk in sks]
+    host = tfhe.MKCloudKey(parts)                        # numpy expansion
+    dev = tfhe.MKCloudKey(parts, expand="device")
+    assert np.array_equal(dev.bootstrap_key, host.bootstrap_key)
+    o = orc.Oracle(n, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=parties)
+    o.load_bootstrap_key(host.bootstrap_key)
+    o.load_keyswitch_key(host.keyswitch_key)
+    x = tfhe.mk_encrypt(rng, sks, [True, False, True])
+    y = tfhe.mk_encrypt(rng, sks, [True, True, False])
+    assert np.array_equal(tfhe.mk_gate_nand(dev, x, y), o.mk_gate_nand(x, y, nthreads=3))
+    host.close()
+    dev.close()

@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
+    "tfhe_mk_expand_load_bootstrap_key",
 ]
 ABI_VERSION = 2
 
@@ -70,6 +71,7 @@ def load():
     lib.tfhe_mk_load_bootstrap_key_i32.argtypes = [vp, vp, i32]
     lib.tfhe_mk_load_keyswitch_key.argtypes = [vp, vp, i32]
     lib.tfhe_mk_load_bootstrap_key_c128.argtypes = [vp, vp, i32]
+    lib.tfhe_mk_expand_load_bootstrap_key.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tfhe_mk_gate_nand_batch.argtypes = [vp, vp, vp, vp, i64]
     lib.tfhe_last_timing_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
     lib.tfhe_last_rotation_count.argtypes = [vp]
@@ -264,6 +266,21 @@ class Engine:
             raise ValueError(f"multi-key bootstrap spectra have {sp.size} values, expected {want} for {P} parties")
         self._check(self._lib.tfhe_mk_load_bootstrap_key_c128(self._h, _ptr(sp), P))
         self._mk_parties = P
+
+    def mk_expand_load_bootstrap_key(self, parties, pub_b, c0, c1, d0, d1, f0, f1, want_expanded=False):
+        """RGSW.Expand on the device (tfhe_mk_expand_load_bootstrap_key).  pub_b: [P][l][N]; c0 .. f1: [P][n][l][N].
+        Returns the expanded Int32 key [P][n][2lP + 2l][N] if want_expanded."""
+        P, l = int(parties), self.params.bs_decomp_length
+        arrs = [_i32c(a) for a in (pub_b, c0, c1, d0, d1, f0, f1)]
+        if arrs[0].shape != (P, l, self.N):
+            raise ValueError(f"public keys must be [{P}][{l}][{self.N}], got {arrs[0].shape}")
+        for a in arrs[1:]:
+            if a.shape != (P, self.n, l, self.N):
+                raise ValueError(f"uni-encryption arrays must be [{P}][{self.n}][{l}][{self.N}], got {a.shape}")
+        out = np.empty((P, self.n, 2 * l * P + 2 * l, self.N), np.int32) if want_expanded else None
+        self._check(self._lib.tfhe_mk_expand_load_bootstrap_key(self._h, P, *[_ptr(a) for a in arrs], _ptr(out)))
+        self._mk_parties = P
+        return out
 
     def mk_load_keyswitch_key(self, ks, parties):
         ks = _i32c(ks)

@@ -382,7 +382,7 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
         else if (is_c128)
             hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_bk);
         else
-            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_bk, c->T);
+            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_bk, c->T, 1.0 / kM);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1066,7 +1066,7 @@ static int32_t mk_load_bk_common(tfhe_ctx *c, const void *bk, int32_t parties, b
     hipError_t e = hipMemcpyAsync(d_in, bk, bytes_in, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         if (is_c128) hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_mk_bk);
-        else hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T);
+        else hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T, 1.0 / kM);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1080,6 +1080,90 @@ static int32_t mk_load_bk_common(tfhe_ctx *c, const void *bk, int32_t parties, b
 int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk, int32_t parties) { return mk_load_bk_common(c, bk, parties, false); }
 
 int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra, int32_t parties) { return mk_load_bk_common(c, bk_spectra, parties, true); }
+
+// RGSW.Expand on the device (mk_internals.jl:304-345, MKBootstrapKey :442-461): the parties' uni-encryptions and public
+// keys in, the expanded transformed bootstrapping key resident on the device out.
+int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const int32_t *pub_b, const int32_t *c0, const int32_t *c1,
+                                          const int32_t *d0, const int32_t *d1, const int32_t *f0, const int32_t *f1, int32_t *expanded_out)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (!pub_b || !c0 || !c1 || !d0 || !d1 || !f0 || !f1) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_expand: NULL argument");
+    if (parties < 2 || parties > 8 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_expand: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
+    if (c->multi()) {
+        // (the expanded key is written to the caller's buffer by the first device only)
+        return fan_out(c, all_kids(c), [&](int k) {
+            return tfhe_mk_expand_load_bootstrap_key(c->kids[(size_t)k], parties, pub_b, c0, c1, d0, d1, f0, f1, k == 0 ? expanded_out : nullptr);
+        });
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = c->P.n, l = c->P.bs_l, P = parties;
+    const size_t per = (size_t)2 * l * P + 2 * l;
+    const size_t npolys = (size_t)P * n * per;
+    const size_t nl = (size_t)n * l;                   // polys per party in each of c0 .. f1
+    c->have_mk_bk = false;
+    if (c->d_mk_bk) { (void)hipFree(c->d_mk_bk); c->d_mk_bk = nullptr; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * kM * sizeof(cplx)));
+    // scratch: the party's 6 uni-encryption arrays, the digit polynomials and their spectra, f0 / f1 spectra, the party's key slice
+    int32_t *d_in = nullptr, *d_dec = nullptr, *d_key = nullptr;
+    cplx *d_decs = nullptr, *d_fs = nullptr;
+    const size_t ndec = (size_t)(P - 1) * l * l;
+    auto cleanup = [&]() {
+        if (d_in) (void)hipFree(d_in);
+        if (d_dec) (void)hipFree(d_dec);
+        if (d_key) (void)hipFree(d_key);
+        if (d_decs) (void)hipFree(d_decs);
+        if (d_fs) (void)hipFree(d_fs);
+    };
+    auto body = [&]() -> int32_t {
+        HIP_TRY(c, hipMalloc((void **)&d_in, 6 * nl * kN * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_dec, ndec * kN * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_decs, ndec * kM * sizeof(cplx)));
+        HIP_TRY(c, hipMalloc((void **)&d_fs, 2 * nl * kM * sizeof(cplx)));
+        HIP_TRY(c, hipMalloc((void **)&d_key, (size_t)n * per * kN * 4));
+        std::vector<int32_t> h_dec(ndec * kN);
+        hipStream_t s = c->stream;
+        for (int i = 0; i < P; i++) {
+            // g^-1(b_q[jj] - b_i[jj])[u] for every other party q (tgsw.jl:99-117): [oq][u][jj][N]
+            int oq = 0;
+            for (int q = 0; q < P; q++) {
+                if (q == i) continue;
+                for (int jj = 0; jj < l; jj++) {
+                    const int32_t *bq = pub_b + ((size_t)q * l + jj) * kN, *bi = pub_b + ((size_t)i * l + jj) * kN;
+                    for (int t = 0; t < kN; t++) {
+                        const int32_t v = (int32_t)((uint32_t)bq[t] - (uint32_t)bi[t] + (uint32_t)c->g.offset);
+                        for (int u = 0; u < l; u++) h_dec[(((size_t)oq * l + u) * l + jj) * kN + t] = gadget_digit(v, u + 1, c->g);
+                    }
+                }
+                oq++;
+            }
+            const int32_t *src[6] = {c0, c1, d0, d1, f0, f1};
+            for (int a = 0; a < 6; a++)
+                HIP_TRY(c, hipMemcpyAsync(d_in + (size_t)a * nl * kN, src[a] + (size_t)i * nl * kN, nl * kN * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(d_dec, h_dec.data(), ndec * kN * 4, hipMemcpyHostToDevice, s));
+            const int32_t *dc0 = d_in, *dc1 = d_in + nl * kN, *dd0 = d_in + 2 * nl * kN, *dd1 = d_in + 3 * nl * kN, *df = d_in + 4 * nl * kN;
+            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)ndec), dim3(64), 0, s, (const int32_t *)d_dec, d_decs, c->T, 1.0);
+            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)(2 * nl)), dim3(64), 0, s, df, d_fs, c->T, 1.0 / kM);     // f0 then f1
+            MkExpandArgs A;
+            A.dec = d_decs; A.f = d_fs; A.d0 = dd0; A.key = d_key; A.T = c->T; A.n = n; A.l = l; A.parties = P; A.party = i;
+            hipLaunchKernelGGL(mk_expand_kernel, dim3((unsigned)n, (unsigned)(l * (P - 1)), 2), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(mk_expand_copy_kernel, dim3((unsigned)n, (unsigned)l, 4), dim3(256), 0, s, dc0, dc1, dd0, dd1, d_key, n, l, P, i);
+            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)((size_t)n * per)), dim3(64), 0, s, (const int32_t *)d_key,
+                               c->d_mk_bk + (size_t)i * n * per * kM, c->T, 1.0 / kM);
+            HIP_TRY(c, hipGetLastError());
+            if (expanded_out)
+                HIP_TRY(c, hipMemcpyAsync(expanded_out + (size_t)i * n * per * kN, d_key, (size_t)n * per * kN * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));      // h_dec and the scratch buffers are reused by the next party
+        }
+        return TFHE_OK;
+    };
+    const int32_t rc = body();
+    cleanup();
+    if (rc) return rc;
+    c->mk_parties = parties;
+    c->have_mk_bk = true;
+    return TFHE_OK;
+}
 
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parties)
 {

@@ -61,13 +61,28 @@ class CloudKeyPart:
 
 
 class MKCloudKey:
-    """mk_api.jl:83-101 — expands the parts (RGSW.Expand, mk_internals.jl:304-345) into the flat key."""
+    """mk_api.jl:83-101 — expands the parts (RGSW.Expand, mk_internals.jl:304-345) into the flat key.
 
-    def __init__(self, ck_parts):
+    expand="host" (default): numpy, as the reference does it on the CPU; `.bootstrap_key` is the flat Int32 key.
+    expand="device": the parts are kept as they are and every engine expands them on its GPU when it is created
+    (tfhe_mk_expand_load_bootstrap_key) — what makes the full-size 4- and 8-party sets (mk_api.jl:16-34: up to
+    3.6 M polynomial products, a 2.4 GB key) practical; `.bootstrap_key` is then fetched from the device on demand."""
+
+    def __init__(self, ck_parts, expand="host"):
         p = ck_parts[0].params
         self.params = p
-        P = self.parties = len(ck_parts)
-        assert P <= p.max_parties                                       # mk_api.jl:94
+        self.parties = len(ck_parts)
+        assert self.parties <= p.max_parties                            # mk_api.jl:94
+        assert expand in ("host", "device")
+        self.expand = expand
+        self._parts = ck_parts
+        self._bootstrap_key = self._expand_on_host() if expand == "host" else None
+        self.keyswitch_key = np.stack([part.ks for part in ck_parts])   # [P][N][t][base-1][n+1]
+        self._engines = {}
+
+    def _expand_on_host(self):
+        ck_parts = self._parts
+        p, P = self.params, self.parties
         N, l, n, beta = p.tlwe_polynomial_degree, p.bs_decomp_length, p.lwe_size, p.bs_log2_base
         per = 2 * l * P + 2 * l
         bk = np.zeros((P, n, per, N), np.int32)
@@ -94,16 +109,33 @@ class MKCloudKey:
             bk[i, :, l * P:2 * l * P] = wrap32(y).reshape(n, l * P, N)
             bk[i, :, 2 * l * P:2 * l * P + l] = part.c0
             bk[i, :, 2 * l * P + l:] = part.c1
-        self.bootstrap_key = bk
-        self.keyswitch_key = np.stack([part.ks for part in ck_parts])   # [P][N][t][base-1][n+1]
-        self._engines = {}
+        return bk
+
+    def _part_arrays(self):
+        parts = self._parts
+        return [np.stack([part.public_b for part in parts])] + [np.stack([getattr(part, name) for part in parts])
+                                                               for name in ("c0", "c1", "d0", "d1", "f0", "f1")]
+
+    @property
+    def bootstrap_key(self):
+        """Flat Int32 key [P][n][2lP + 2l][N] (host expansion, or downloaded from a device that expanded it)."""
+        if self._bootstrap_key is None:
+            e = _lib.Engine(self.params, 0)
+            try:
+                self._bootstrap_key = e.mk_expand_load_bootstrap_key(self.parties, *self._part_arrays(), want_expanded=True)
+            finally:
+                e.close()
+        return self._bootstrap_key
 
     def engine(self, device=0):
         key = device if np.ndim(device) == 0 else tuple(int(d) for d in device)
         e = self._engines.get(key)
         if e is None:
             e = _lib.Engine(self.params, device) if np.ndim(device) == 0 else _lib.Engine(self.params, devices=list(key))
-            e.mk_load_bootstrap_key(self.bootstrap_key, self.parties)
+            if self.expand == "device":
+                e.mk_expand_load_bootstrap_key(self.parties, *self._part_arrays())
+            else:
+                e.mk_load_bootstrap_key(self.bootstrap_key, self.parties)
             e.mk_load_keyswitch_key(self.keyswitch_key, self.parties)
             self._engines[key] = e
         return e

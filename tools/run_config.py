@@ -79,7 +79,7 @@ def single_key(params, B, reps, seed, want_diag, label):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", required=True, choices=["1", "2host", "3", "4a", "4b", "5", "k2"])
+    ap.add_argument("--config", required=True, choices=["1", "2host", "3", "4a", "4b", "5", "k2", "mk4", "mk8"])
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--gates", type=int, default=0)
     ap.add_argument("--no-diag", action="store_true")
@@ -114,6 +114,39 @@ def main():
                "rotations": eng.last_rotation_count(), "blind_rotate_ms": eng.last_timing_ms(0), "keyswitch_ms": eng.last_timing_ms(1),
                "rot_per_s": eng.last_rotation_count() / eng.last_timing_ms(0) * 1e3, "host_wall_ms": wall * 1e3}
         ck.close()
+    elif a.config in ("mk4", "mk8"):   # full-size 4- / 8-party sets (mk_api.jl:16-34), key expanded on the device
+        p = tfhe.mktfhe_parameters_4party if a.config == "mk4" else tfhe.mktfhe_parameters_8party
+        if a.lwe_size:
+            p = tfhe.SchemeParameters(a.lwe_size, p.lwe_noise_stddev, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.bs_noise_stddev, 8, 2, p.ks_noise_stddev, p.max_parties)
+        P = p.max_parties
+        mrng = np.random.default_rng(321)
+        t0 = time.perf_counter()
+        sks = [tfhe.SecretKey(mrng, p) for _ in range(P)]
+        shared = tfhe.SharedKey(mrng, p)
+        parts = [tfhe.CloudKeyPart(mrng, s, shared) for s in sks]
+        t_parts = time.perf_counter() - t0
+        mck = tfhe.MKCloudKey(parts, expand="device")
+        t0 = time.perf_counter()
+        em = mck.engine(0)
+        t_expand = time.perf_counter() - t0
+        apply_options(em)
+        B = a.gates or 1024
+        m1, m2 = mrng.integers(0, 2, B).astype(bool), mrng.integers(0, 2, B).astype(bool)
+        xm, ym = tfhe.mk_encrypt(mrng, sks, m1), tfhe.mk_encrypt(mrng, sks, m2)
+        out = em.mk_gate_nand(xm, ym)
+        br, ks = [], []
+        def call():
+            em.mk_gate_nand(xm, ym); br.append(em.last_timing_ms(0)); ks.append(em.last_timing_ms(1))
+        wall = timed_calls(call, max(1, a.reps - 1))
+        brm = float(np.median(br))
+        res = {"config": f"{P}-party MK NAND (mk_api.jl:16-34), key expanded on the device", "gates": B, "kernel": em.last_kernel_name(),
+               "host_keygen_parts_s": t_parts, "device_expand_and_load_s": t_expand, "blind_rotate_ms": brm, "keyswitch_ms": float(np.median(ks)),
+               "host_wall_ms": wall * 1e3, "gates_per_s_host_buffers": B / wall, "rot_per_s": B / brm * 1e3, "bytes_per_rotation": br_bytes(p, P),
+               "frac_hbm_algorithmic": B / brm * 1e3 * br_bytes(p, P) / HBM_PEAK,
+               "decrypt_ok_fraction": float((tfhe.mk_decrypt(sks, out) == ~(m1 & m2)).mean())}
+        if want_diag:
+            res.update(diag(em, lambda: em.mk_gate_nand(xm[:64], ym[:64]), seconds=0.1))
+        mck.close()
     else:   # 5: 2-party MK NAND
         p = tfhe.mktfhe_parameters_2party
         if a.lwe_size:
