@@ -122,6 +122,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # One explicit stream for everything: the engine's kernels are launched on it (a NULL stream would mean the context's
+    # own private stream), and torch's copies and the RCCL gather order themselves against torch's CURRENT stream.
+    work_stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(work_stream)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
@@ -140,7 +144,7 @@ def main():
 
     # --- inputs: encryptions of i.i.d. uniform bits, seed 456 (+rank), uploaded before timing -------
     n1 = params.lwe_size + 1
-    from tfhe_jl_amd.sharding import gather_to_root, shard_bounds
+    from tfhe_jl_amd.sharding import shard_bounds
     parts = 1 if args.fanout else world          # shards handled by separate processes
     if args.workload == "nand":
         B = args.gates * (n_gpus if args.fanout else 1)
@@ -170,23 +174,87 @@ def main():
     use_gather = world > 1 and not args.no_gather
     if not args.fanout:
         dx, dy, dz = (torch.from_numpy(h).to(dev) for h in (hx, hy, hz))
-        dout = torch.empty((B, n1), dtype=torch.int32, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        # two result buffers: the gather of step i (a point-to-point transfer to rank 0 over xGMI) overlaps step i + 1
+        douts = [torch.empty((B, n1), dtype=torch.int32, device=dev) for _ in range(2)]
+        dout = douts[0]
+        stream = work_stream.cuda_stream
+        assert stream, "the engine must be given torch's current stream explicitly"
     host_out = None
-    gathered = None
     br_ms, ks_ms = [], []
 
+    class RootGather:
+        """One gather of the shards' results to rank 0 per step, asynchronous: everything is allocated up front, shards
+        are padded to the longest one, rank 0 keeps the received parts.  Transport: RCCL (`dist.gather` = grouped
+        send/recv to the root); on a one-GPU rehearsal gloo on host copies.  If this build's RCCL backend rejects
+        `gather`, the plain all_gather (every rank receives everything) is used instead and the JSON line says so."""
+
+        def __init__(self):
+            self.longest = max(e - s for s, e in bounds)
+            self.mode = "gather"
+            tdev = "cpu" if share_gpu else dev
+            self.padded = [torch.zeros((self.longest, n1), dtype=torch.int32, device=tdev) for _ in range(2)]
+            self.parts = [[torch.empty((self.longest, n1), dtype=torch.int32, device=tdev) for _ in range(world)] if rank == 0 else None
+                          for _ in range(2)]
+            self.full = None
+            self.pending = [None, None]
+
+        def wait(self, k):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+        def launch(self, k, src):
+            if share_gpu:
+                self.padded[k][:B].copy_(src)                 # D2H (synchronous): rehearsal only
+                send = self.padded[k]
+            elif B == self.longest:
+                send = src
+            else:
+                self.padded[k][:B].copy_(src)
+                send = self.padded[k]
+            if self.mode == "gather":
+                try:
+                    self.pending[k] = dist.gather(send, self.parts[k], dst=0, async_op=True)
+                    return
+                except (RuntimeError, NotImplementedError) as e:   # backend without gather: fall back, loudly
+                    print(f"bench.py: dist.gather unavailable ({e}); using all_gather", file=sys.stderr)
+                    self.mode = "all_gather"
+            if self.full is None:
+                self.full = [torch.empty((world * self.longest, n1), dtype=torch.int32, device=send.device) for _ in range(2)]
+            self.pending[k] = dist.all_gather_into_tensor(self.full[k], send, async_op=True)
+
+        def result(self, k):
+            """Rank 0: the gathered [total][n+1] result of buffer k (after wait)."""
+            if rank != 0:
+                return None
+            if self.mode == "gather":
+                return torch.cat([self.parts[k][r][: e - s] for r, (s, e) in enumerate(bounds)], dim=0)
+            return torch.cat([self.full[k][r * self.longest: r * self.longest + (e - s)] for r, (s, e) in enumerate(bounds)], dim=0)
+
+    gatherer = RootGather() if (use_gather and not args.fanout) else None
+    step_no = 0
+
     def step(record):
-        nonlocal host_out, gathered
+        nonlocal host_out, dout, step_no
         if args.fanout:
             host_out = eng.gates(ops, hx, hy, hz if args.workload == "mixed" else None)
         else:
+            k = step_no & 1
+            step_no += 1
+            dout = douts[k]
+            if gatherer:
+                gatherer.wait(k)          # the gather that read this buffer two steps ago
             eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
-            if use_gather:   # one RCCL gather of the shards' results to rank 0 (rehearsal on one GPU: gloo on host copies)
-                gathered = gather_to_root(dout.cpu() if share_gpu else dout, bounds, rank, dst=0)
+            if gatherer:
+                gatherer.launch(k, dout)
         if record:
             br_ms.append(eng.last_timing_ms(0))   # HIP events on the stream the kernels were launched on
             ks_ms.append(eng.last_timing_ms(1))
+
+    def drain():
+        if gatherer:
+            gatherer.wait(0)
+            gatherer.wait(1)
 
     def barrier():
         if world > 1:
@@ -195,10 +263,12 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
@@ -212,8 +282,8 @@ def main():
     out = host_out if args.fanout else dout.cpu().numpy()
     ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), expect))
     gather_ok = None
-    if use_gather and rank == 0:
-        g = gathered.cpu().numpy()
+    if gatherer and rank == 0:
+        g = gatherer.result((step_no - 1) & 1).cpu().numpy()
         s0, e0 = bounds[0]
         gather_ok = bool(g.shape[0] == bounds[-1][1] and np.array_equal(g[s0:e0], out))
 
@@ -285,7 +355,8 @@ def main():
                 "launch": ("one process, multi-device context (tfhe_ctx_create_multi)" if args.fanout else
                            "one process per GPU (torch.distributed)" if world > 1 else "one process"),
                 "result_gather": ("none (results written into the caller's host buffer)" if args.fanout else
-                                  ("gloo gather to rank 0 (one-GPU rehearsal)" if share_gpu else "rccl gather to rank 0") if use_gather else "none"),
+                                  (("gloo " if share_gpu else "rccl ") + (gatherer.mode if gatherer else "gather") + " to rank 0, overlapped with the next step"
+                                   + (" (one-GPU rehearsal)" if share_gpu else "")) if use_gather else "none"),
             },
             "outputs_decrypt_correctly": ok_decrypt,
             "gather_matches_local_shard": gather_ok,
