@@ -151,3 +151,28 @@ def test_device_rgsw_expand_equals_host(orc, tfhe, which, parties, n):
     assert np.array_equal(tfhe.mk_gate_nand(dev, x, y), o.mk_gate_nand(x, y, nthreads=3))
     host.close()
     dev.close()
+
+
+@pytest.mark.gpu
+def test_mk_four_party_full_size_sample(orc, tfhe):
+    """mktfhe_parameters_4party at its shipped size (mk_api.jl:16-22: n = 500, l = 5, beta = 6): the key is expanded on
+    the device (RGSW.Expand), downloaded for the oracle, and a sample of NAND gates is compared word for word; every
+    output decrypts (2000 CMUX steps, 30 forward transforms each, through mk_blind_rotate_kernel_general)."""
+    p = tfhe.mktfhe_parameters_4party
+    rng = np.random.default_rng(4444)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(4)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks], expand="device")
+    eng = ck.engine(0)
+    B = 64
+    m1, m2 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.mk_encrypt(rng, sks, m1), tfhe.mk_encrypt(rng, sks, m2)
+    got = eng.mk_gate_nand(x, y)
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_general(P=4,L=5)"
+    assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.95
+    o = orc.Oracle(p.lwe_size, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=4)
+    o.load_bootstrap_key(ck.bootstrap_key)          # the device-expanded key, downloaded
+    o.load_keyswitch_key(ck.keyswitch_key)
+    idx = [0, 1, 31, 63]
+    assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=4))
+    ck.close()
