@@ -48,11 +48,15 @@ def _check(eng, K, x, expect_kernel, what):
 
 @pytest.mark.parametrize("l", [1, 2, 3, 4])
 def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
-    """blind_rotate_kernel_v3<l,16> (large batches), v3<l,8>, w2<l> (<= 512 rotations), baseline <l,2>: k = 1, N = 1024."""
+    """blind_rotate_kernel_v3<l,16> (large batches), v3<l,8>, w2<l> (<= 512 rotations), h2<l> (<= 8 rotations, l <= 3),
+    baseline <l,2>: k = 1, N = 1024."""
     K = _setup(tfhe, orc, 1024, 1, l, BETA_1024[l])
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(l), 6, K.params.lwe_size + 1)
-    _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")        # the default for a batch this small
+    if l <= 3:
+        _check(eng, K, x, f"blind_rotate_kernel_h2<{l}>", f"h2<{l}>")    # the default for a batch this small
+    eng.set_option("br_tiny", -1)
+    _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
     eng.set_option("br_small", -1)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},16>", f"v3<{l},16>")
     eng.set_option("br_variant", 3)
@@ -66,11 +70,13 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
     eng.set_option("br_variant", 2)
     # the switch between the two kernels is by batch size: 513 rotations take v3<l,16> without any option
+    eng.set_option("br_tiny", 8)
     big = np.repeat(x[2:3], 513, axis=0)
     big[:, 0] += np.arange(513, dtype=np.int32) << 21        # distinct first exponents
-    idx = [0, 1, 255, 256, 511, 512]
+    idx = [0, 1, 7, 8, 511, 512]
     want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=6)
-    for rows, kernel in ((512, f"blind_rotate_kernel_w2<{l}>"), (513, f"blind_rotate_kernel_v3<{l},16>")):
+    for rows, kernel in ((8, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (9, f"blind_rotate_kernel_w2<{l}>"),
+                         (512, f"blind_rotate_kernel_w2<{l}>"), (513, f"blind_rotate_kernel_v3<{l},16>")):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
         sel = [j for j, r in enumerate(idx) if r < rows]

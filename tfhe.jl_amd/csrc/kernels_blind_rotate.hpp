@@ -61,6 +61,16 @@ __device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double wor
     }
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the body needs I as a constant expression)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 struct BrArgs {
     DiagArgs diag;
     const int32_t *bara;  // [R][n+1], barb last
@@ -539,14 +549,14 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 // ---- multi-key blind rotation, 2 parties, TWO waves per rotation ------------------------------------------------
 // BASELINE config 5 is 1024 rotations: with one wave per rotation that is ONE wave per SIMD (a lone wave issues FP64 at
 // about half the SIMD's rate) running 12 forward and 3 inverse transforms per step back to back.  Here the two waves of
-// a workgroup split the decomposition digits: wave w transforms digits p in [w L/2, (w+1) L/2) of all three source
-// polynomials (a_0, a_1, b) and multiplies them into its own partial sums of the three new polynomials
-// (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
+// a workgroup split the 3 L forward transforms of a step evenly (wave 0: every digit of the party's mask and half the
+// digits of the other mask; wave 1: every digit of the body and the other half) and multiply them into their own
+// partial sums of the three new polynomials (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
 // wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
 // polynomials.  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
 // reuses the transposition buffers).  Same words as mk_blind_rotate_kernel.  L must be even.
-template <int L, int PARTY, bool MARGIN>
-__device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
+template <int L, int PARTY, int WV, bool MARGIN>
+__device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                 cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
                                                 int32_t xormask, double &worst)
 {
@@ -554,7 +564,6 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
     constexpr int OTHER = 1 - PARTY;
     const int beta = P.g.log2_base;
-    const int p0 = wv * (L / 2);                  // this wave's digits: p0 .. p0 + L/2 - 1
     int a_next = bara[PARTY * P.n] & (2 * kN - 1);
     STAMP_DECL;
 #pragma unroll 1
@@ -562,13 +571,18 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
         const int a = a_next;
         a_next = bara[PARTY * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
         const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
-        cplx out[NP + 1][8];                      // partial sums of the new a_0, a_1, b over this wave's digits
+        cplx out[NP + 1][8];                      // partial sums of the new a_0, a_1, b over this wave's transforms
 #pragma unroll
         for (int d = 0; d <= NP; d++)
 #pragma unroll
             for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
-#pragma unroll
-        for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
+        // Work split (12 forward transforms per step): wave 0 takes all L digits of the party's mask and digits
+        // [0, L/2) of the other mask, wave 1 all L digits of the body and digits [L/2, L) of the other mask: each wave
+        // rotates and decomposes two source polynomials instead of three.
+        static_for<0, 2>([&](auto job_c) {
+            constexpr int job = decltype(job_c)::value;
+            constexpr int s = job == 0 ? (WV == 0 ? PARTY : NP) : OTHER;      // source polynomial
+            constexpr int p_begin = job == 0 ? 0 : WV * (L / 2), p_end = job == 0 ? L : (WV + 1) * (L / 2);
             int32_t temp[16];
             {
                 int32_t cur[16];
@@ -580,17 +594,16 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
             }
             STAMP(0);
 #pragma unroll 1
-            for (int pp = 0; pp < L / 2; pp++) {
-                const int p = p0 + pp;
-                const cplx *k_party, *k_body, *k_other = nullptr;
+            for (int p = p_begin; p < p_end; p++) {
+                const cplx *k_party, *k_body;
                 if (s < NP) {
                     k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
                     k_body = key + (size_t)(p * NP + s) * kM;                   // x[p, s]      -> b'
-                    if (s != PARTY) k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;   // y[p, party] -> a'_s
                 } else {
                     k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
                     k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
                 }
+                const cplx *k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;           // y[p, party] -> a'_other (s == OTHER only)
                 cplx kpa[8];                      // requested before the FFT (a second poly in flight spills)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_party[k2 * 64];
@@ -615,10 +628,10 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
                 }
                 STAMP(2);
             }
-        }
+        });
         // hand-off: each wave writes what the other one owns into its OWN transposition buffer (+ the extra slot), so
         // nothing of the other wave's is touched before the barrier
-        if (wv == 0) {
+        if (WV == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) xch_own[k2 * 64 + lane] = out[NP][k2];
         } else {
@@ -628,7 +641,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
         STAMP(3);
         __syncthreads();
         STAMP(4);
-        if (wv == 0) {
+        if (WV == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) { out[0][k2] = cadd(out[0][k2], xch_oth[k2 * 64 + lane]); out[1][k2] = cadd(out[1][k2], extra[k2 * 64 + lane]); }
         } else {
@@ -646,13 +659,13 @@ __device__ __forceinline__ void mk2_party_steps(int lane, int wv, const MkBrArgs
             untwist_add2<MARGIN>(o, accr, &worst);
             store_acc<2>(lane, accr, acc_lds + d * kN);
         };
-        if (wv == 0) { finish(out[0], 0); finish(out[1], 1); }
+        if (WV == 0) { finish(out[0], 0); finish(out[1], 1); }
         else finish(out[NP], NP);
         STAMP(7);
         __syncthreads();      // the updated accumulator is visible to both waves' rotations of the next step
         STAMP(8);
     }
-    if (PARTY == 1) STAMP_FLUSH(P.diag, wv);
+    if (PARTY == 1) STAMP_FLUSH(P.diag, WV);
 }
 
 template <int L, bool MARGIN = false>
@@ -689,8 +702,13 @@ __global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
     }
     __syncthreads();
     // party-major double loop (mk_internals.jl:475-476)
-    mk2_party_steps<L, 0, MARGIN>(lane, wv, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
-    mk2_party_steps<L, 1, MARGIN>(lane, wv, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+    if (wv == 0) {
+        mk2_party_steps<L, 0, 0, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+        mk2_party_steps<L, 1, 0, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+    } else {
+        mk2_party_steps<L, 0, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+        mk2_party_steps<L, 1, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+    }
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
@@ -953,6 +971,264 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
     }
 }
 
+// ---- smallest batches: every transform split over two waves ------------------------------------------
+// A lone wave issues FP64 at about half its SIMD's rate, so the latency of a CMUX step is set by the number of
+// instructions ONE wave runs back to back; giving every transform its own wave (measured) does not help because the step
+// is then one forward + one inverse 512-point transform long.  Here each 512-point transform is split over TWO waves
+// by a radix-2 decimation in frequency,
+//     even frequencies 2k':  FFT256(a),  a_j = z_j + z_{j+256}          odd 2k'+1:  FFT256(b),  b_j = (z_j - z_{j+256}) w^j,
+// and each half is a 256-point transform with FOUR points per lane (four radix-4 passes, three wave-private LDS
+// transposes of 4 KB).  A rotation is 4 L waves: wave (p, c, h) rotates and decomposes accumulator polynomial c,
+// transforms half h of digit p, multiplies into partial sums of both output components, hands them to the owner
+// of (co, h) = wave (0, co, h), which sums, inverse-transforms its half, swaps halves with its partner (h ^ 1) and
+// updates half of the coefficients of polynomial co.  Three barriers per step.
+// Layouts: lane t, register r <-> point j = t + 64 r (j < 256) on input;
+//          lane (q, q2, q3) = 16 q + 4 q2 + q3, register q4 <-> half-spectrum index k' = q + 4 q2 + 16 q3 + 64 q4 on output.
+struct H2Tables {
+    const cplx *tw1h;   // [2 (h)][4 (q)][64 (t)]   e^{-i pi t/N} * (h ? e^{-2 pi i t/512} : 1) * e^{-2 pi i t q/256}
+    const cplx *tw2q;   // [4 (q2)][16 (t1)]        e^{-2 pi i t1 q2/64}
+    const cplx *tw3q;   // [4 (q3)][4 (t2)]         e^{-2 pi i t2 q3/16}
+};
+constexpr int kH2TableElems = 2 * 4 * 64 + 4 * 16 + 4 * 4;
+constexpr int kH2Buf = 320;          // cplx per wave: transposition buffer (padded 4 x 80)
+
+template <bool INV>
+__device__ __forceinline__ void dft4(cplx (&x)[4])
+{
+    const cplx a = cadd(x[0], x[2]), b = csub(x[0], x[2]), c = cadd(x[1], x[3]), d = csub(x[1], x[3]);
+    const cplx id = INV ? mk(-d.y, d.x) : mk(d.y, -d.x);      // forward: -i d, inverse: +i d
+    x[0] = cadd(a, c); x[2] = csub(a, c); x[1] = cadd(b, id); x[3] = csub(b, id);
+}
+
+struct H2LaneTw { cplx tw1[4], tw2[4], tw3[4]; };
+
+__device__ __forceinline__ void fft256_fwd(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb)
+{
+    dft4<false>(x);
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = cmul(x[q], w.tw1[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) tb[q * 64 + lane] = x[q];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = tb[(lane >> 4) * 64 + (lane & 15) + 16 * r];
+    WAVE_LDS_FENCE();
+    dft4<false>(x);
+#pragma unroll
+    for (int q = 1; q < 4; q++) x[q] = cmul(x[q], w.tw2[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) tb[(lane >> 4) * 80 + q * 20 + (lane & 15)] = x[q];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = tb[(lane >> 4) * 80 + ((lane >> 2) & 3) * 20 + (lane & 3) + 4 * r];
+    WAVE_LDS_FENCE();
+    dft4<false>(x);
+#pragma unroll
+    for (int q = 1; q < 4; q++) x[q] = cmul(x[q], w.tw3[q]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) tb[(lane >> 2) * 20 + q * 5 + (lane & 3)] = x[q];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int r = 0; r < 4; r++) x[r] = tb[(lane >> 2) * 20 + (lane & 3) * 5 + r];
+    WAVE_LDS_FENCE();
+    dft4<false>(x);
+}
+
+__device__ __forceinline__ void fft256_inv(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb)
+{
+    dft4<true>(x);
+#pragma unroll
+    for (int r = 0; r < 4; r++) tb[(lane >> 2) * 20 + (lane & 3) * 5 + r] = x[r];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = tb[(lane >> 2) * 20 + q * 5 + (lane & 3)];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 1; q < 4; q++) x[q] = cmulc(x[q], w.tw3[q]);
+    dft4<true>(x);
+#pragma unroll
+    for (int r = 0; r < 4; r++) tb[(lane >> 4) * 80 + ((lane >> 2) & 3) * 20 + (lane & 3) + 4 * r] = x[r];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = tb[(lane >> 4) * 80 + q * 20 + (lane & 15)];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 1; q < 4; q++) x[q] = cmulc(x[q], w.tw2[q]);
+    dft4<true>(x);
+#pragma unroll
+    for (int r = 0; r < 4; r++) tb[(lane >> 4) * 64 + (lane & 15) + 16 * r] = x[r];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = tb[q * 64 + lane];
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = cmulc(x[q], w.tw1[q]);
+    dft4<true>(x);
+}
+
+// (Measured dead end: letting the two waves of a transform each rotate and decompose only half of the lane's points and
+//  swap the twisted points through LDS saves a quarter of the forward instructions but costs a fourth barrier: 1.76 ms
+//  against 1.70 ms per gate.)
+template <int L, bool MARGIN = false>
+__global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H2Tables HT)
+{
+    constexpr int K1 = 2, W = 2 * K1 * L;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
+    cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                 // [W][kH2Buf]
+    cplx *extra_all = tb_all + W * kH2Buf;                                       // [W][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = tid >> 6;                                                     // wave = (p, c, h): owners (p = 0) are waves 0..3, one per SIMD
+    const int h = wv & 1, c = (wv >> 1) & 1, p = wv >> 2;
+    const bool owner = (p == 0);                                                 // owns half h of output component co = c
+    int32_t *acc_lds = acc_all + c * kN;
+    cplx *tb = tb_all + wv * kH2Buf, *extra = extra_all + wv * 256;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+    const double rs = 0.70710678118654752440;
+
+    H2LaneTw tw;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        tw.tw1[q] = HT.tw1h[(h * 4 + q) * 64 + lane];
+        tw.tw2[q] = HT.tw2q[q * 16 + (lane & 15)];
+        tw.tw3[q] = HT.tw3q[q * 4 + (lane & 3)];
+    }
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+        for (int j = tid; j < kN; j += 256 * L) {
+            const int idx = (j + barb) & (2 * kN - 1);
+            acc_all[j] = 0;
+            acc_all[kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
+    __syncthreads();
+
+    // this lane's four frequencies f = 2 k' + h, k' = q + 4 q2 + 16 q3 + 64 q4: in the key's (v3) order frequency f sits
+    // at element (f >> 6) * 64 + (f & 7) * 8 + ((f >> 3) & 7); f = f0 + 128 q4 keeps f & 63
+    const int f0 = 2 * ((lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3)) + h;
+    const int koff = (f0 >> 6) * 64 + (f0 & 7) * 8 + ((f0 >> 3) & 7);
+    // key polys of transform (p, c): [i][p][c][co][512]; both requested one step ahead of their use
+    const cplx *key_own = P.bk + (size_t)((p * K1 + c) * K1 + c) * kM + koff;          // co = c
+    const cplx *key_oth = P.bk + (size_t)((p * K1 + c) * K1 + (1 - c)) * kM + koff;    // co = 1 - c
+    cplx kown[4], koth[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) { kown[q4] = key_own[q4 * 128]; koth[q4] = key_oth[q4 * 128]; }
+    int a_next = bara[0] & (2 * kN - 1);
+    STAMP_DECL;
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = a_next;
+        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        cplx x[4];
+        int32_t cur[16];                          // this lane's coefficients of polynomial c (an owner adds its half back at the end)
+        {
+            int32_t temp[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
+            rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
+            STAMP(0);
+            cplx x8[8];
+            load_digits2(temp, p + 1, beta, x8);      // (d[t+64r] - i d[t+64r+512]) e^{-i pi r/16}, r < 8
+            if (h == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) x[r] = cadd(x8[r], x8[r + 4]);
+            } else {                                   // (z_r - z_{r+4}) kappa^r, kappa = e^{-i pi/4}
+                const cplx d0 = csub(x8[0], x8[4]), d1 = csub(x8[1], x8[5]), d2 = csub(x8[2], x8[6]), d3 = csub(x8[3], x8[7]);
+                x[0] = d0;
+                x[1] = mk((d1.x + d1.y) * rs, (d1.y - d1.x) * rs);
+                x[2] = mk(d2.y, -d2.x);
+                x[3] = mk((d3.y - d3.x) * rs, -(d3.x + d3.y) * rs);
+            }
+        }
+        STAMP(1);
+        fft256_fwd(lane, x, tw, tb);
+        STAMP(2);
+        cplx own[4], oth[4];                     // this wave's contribution to output component c / 1 - c (half h)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) { own[q4] = cmul(x[q4], kown[q4]); oth[q4] = cmul(x[q4], koth[q4]); }
+        {   // next step's key values (the last step re-reads its own)
+            const size_t step = (size_t)(i + 1 < P.n ? i + 1 : i) * (L * K1 * K1 * kM);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) { kown[q4] = key_own[step + q4 * 128]; koth[q4] = key_oth[step + q4 * 128]; }
+        }
+        // hand-off: the partial for the OTHER component's output goes to this wave's extra slot; a wave that owns nothing
+        // also leaves the one for its own component's output in its transposition buffer (free between transforms)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) extra[q4 * 64 + lane] = oth[q4];
+        if (!owner) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) tb[q4 * 64 + lane] = own[q4];
+        }
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+        if (owner) {
+#pragma unroll
+            for (int ow = h; ow < W; ow += 2) {          // the waves of the same half
+                if (ow == wv) continue;
+                const cplx *src = (((ow >> 1) & 1) == c) ? tb_all + ow * kH2Buf : extra_all + ow * 256;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) own[q4] = cadd(own[q4], src[q4 * 64 + lane]);
+            }
+            STAMP(5);
+            fft256_inv(lane, own, tw, tb);       // a~_r (h = 0) / b~_r (h = 1), lane factors already removed
+            STAMP(6);
+            // swap halves with the partner through the owner's own transposition buffer (nobody else reads it)
+#pragma unroll
+            for (int r = 0; r < 4; r++) tb[r * 64 + lane] = own[r];
+        }
+        __syncthreads();
+        STAMP(7);
+        if (owner) {
+            const cplx *ps = tb_all + (wv ^ 1) * kH2Buf;
+            cplx o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = ps[r * 64 + lane];
+            // g_r8 = (a~_r +- conj(kappa)^r b~_r) conj(c_r8), r8 = r + 4 h; coefficient t + 64 r8 = Re g, + 512: -Im g
+            static_for<0, 4>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const cplx al = h ? o[R] : own[R], be = h ? own[R] : o[R];
+                cplx kb;                              // conj(kappa)^R * be
+                if (R == 0) kb = be;
+                else if (R == 1) kb = mk((be.x - be.y) * rs, (be.x + be.y) * rs);
+                else if (R == 2) kb = mk(-be.y, be.x);
+                else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
+                const cplx wq = h ? csub(al, kb) : cadd(al, kb);
+                const double re0 = wq.x * twc(R) - wq.y * tws(R), im0 = wq.x * tws(R) + wq.y * twc(R);           // conj(c_R)
+                const double re4 = wq.x * twc(R + 4) - wq.y * tws(R + 4), im4 = wq.x * tws(R + 4) + wq.y * twc(R + 4);
+                const double re = h ? re4 : re0, im = h ? im4 : im0;
+                if (MARGIN) {
+                    const double fa = frac_dist(re), fb = frac_dist(im);
+                    worst = fa > worst ? fa : worst;
+                    worst = fb > worst ? fb : worst;
+                }
+                const int jlo = lane + 64 * (R + 4 * h);
+                const int32_t clo = h ? cur[R + 4] : cur[R], chi = h ? cur[R + 12] : cur[R + 8];     // read at rotate time; nobody else writes them
+                acc_lds[jlo] = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
+                acc_lds[jlo + kM] = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+            });
+        }
+        STAMP(8);
+        __syncthreads();     // the updated polynomials are visible to every wave's rotation
+        STAMP(9);
+    }
+    if (wv < 4) STAMP_FLUSH(P.diag, wv);
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    int32_t *ext = P.ext + w * (kN + 1);
+    for (int j = tid; j < kN; j += 256 * L) {
+        const int32_t v = acc_all[j];
+        if (j == 0) ext[0] = v;
+        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (tid == 0) ext[kN] = acc_all[kN];
+}
+
 // ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
 // Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
 // 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
@@ -1064,16 +1340,6 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 //   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
 // Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
 constexpr int kN2 = 2048;
-
-// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the body needs I as a constant expression)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 __host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
 {

@@ -75,6 +75,8 @@ struct tfhe_ctx {
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 512;      // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never)
+    int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
+                                 // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
     int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
 
     // tables
@@ -130,9 +132,11 @@ struct tfhe_ctx {
             return (ctx)->set_err(TFHE_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+constexpr size_t kH2TableOffset = kTableElems + 1024;      // tw1h | tw2q | tw3q of blind_rotate_kernel_h2
+
 static void build_tables(std::vector<cplx> &h)
 {
-    h.resize(kTableElems + 1024);
+    h.resize(kH2TableOffset + kH2TableElems);
     fill_tables<long double>(h.data(), [](long double a) { return cosl(a); }, [](long double a) { return sinl(a); });
     // N = 2048: tw1f2[w][q][t] = e^{-i pi t (1 + 4w + 8q) / 2048}
     const long double pi = 3.14159265358979323846264338327950288L;
@@ -142,6 +146,16 @@ static void build_tables(std::vector<cplx> &h)
                 const long double a = -pi * (long double)(t * (1 + 4 * w + 8 * q)) / 2048.0L;
                 h[kTableElems + w * 512 + q * 64 + t] = mk((double)cosl(a), (double)sinl(a));
             }
+    // split 256-point transforms (blind_rotate_kernel_h2): angles in units of pi
+    auto put = [&](size_t idx, long double turns_of_pi) { const long double a = -pi * turns_of_pi; h[idx] = mk((double)cosl(a), (double)sinl(a)); };
+    for (int hh = 0; hh < 2; hh++)
+        for (int q = 0; q < 4; q++)
+            for (int t = 0; t < 64; t++)      // e^{-i pi t/N} * (h ? e^{-2 pi i t/512} : 1) * e^{-2 pi i t q/256}
+                put(kH2TableOffset + (size_t)(hh * 4 + q) * 64 + t, (long double)t / 1024.0L + (hh ? (long double)t / 256.0L : 0.0L) + (long double)(t * q) / 128.0L);
+    for (int q = 0; q < 4; q++)
+        for (int t = 0; t < 16; t++) put(kH2TableOffset + 512 + (size_t)q * 16 + t, (long double)(t * q) / 32.0L);      // e^{-2 pi i t q/64}
+    for (int q = 0; q < 4; q++)
+        for (int t = 0; t < 4; t++) put(kH2TableOffset + 576 + (size_t)q * 4 + t, (long double)(t * q) / 8.0L);          // e^{-2 pi i t q/16}
 }
 
 static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
@@ -555,6 +569,24 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
 #undef LAUNCH_K2
         HIP_TRY(c, hipGetLastError());
         name_kernel(c, "blind_rotate_kernel_k2<%d>", L);
+        return TFHE_OK;
+    }
+    if ((c->br_tiny >= 0 && (int64_t)R <= c->br_tiny) && c->br_variant >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
+        // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
+        H2Tables ht;
+        ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
+        const size_t ldsh = 2 * kN * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx);
+#define LAUNCH_H2_(LL, DG)                                                                                         \
+        do {                                                                                                       \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_h2<LL, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh)); \
+            hipLaunchKernelGGL((blind_rotate_kernel_h2<LL, DG>), dim3((unsigned)R), dim3(256 * LL), ldsh, s, a, ht); \
+        } while (0)
+#define LAUNCH_H2(LL) do { if (dg) LAUNCH_H2_(LL, true); else LAUNCH_H2_(LL, false); } while (0)
+        BR_CASES(LAUNCH_H2)
+#undef LAUNCH_H2
+#undef LAUNCH_H2_
+        HIP_TRY(c, hipGetLastError());
+        name_kernel(c, "blind_rotate_kernel_h2<%d>", L);
         return TFHE_OK;
     }
     if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2) {
@@ -1479,6 +1511,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
+    if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
     if (!strcmp(name, "ks_slices")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_slices must be 1, 2 or 4");
         c->ks_slices_large = (int)value;

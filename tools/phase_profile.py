@@ -35,7 +35,10 @@ if a.config == "1":
     eng.set_option("measure_margin", 1)
     for _ in range(3): eng.gates(np.zeros(B, np.uint8), x, y)
     print(eng.last_kernel_name(), "BR ms", eng.last_timing_ms(0), "clock", eng.last_kernel_clock_mhz())
-    phases(eng, 500, ["rotate", "digits+fwdFFT", "keywait+MAC", "handoff-write", "barrier", "read+add", "invFFT", "untwist+acc"])
+    if "h2" in eng.last_kernel_name():
+        phases(eng, 500, ["rotate", "digits+combine", "fwdFFT256", "MAC+handoff-write", "barrierA", "read+add", "invFFT256", "swap-write+barrierR", "recombine+acc", "barrierE"])
+    else:
+        phases(eng, 500, ["rotate", "digits+fwdFFT", "keywait+MAC", "handoff-write", "barrier", "read+add", "invFFT", "untwist+acc"])
 elif a.config == "4b":
     p = tfhe.SchemeParameters(630, 1 / 2**15, 2048, 1, 3, 7, 1 / 2**25, 8, 2, 1 / 2**15, 1)
     sk, ck = tfhe.make_key_pair(rng, p)
