@@ -19,7 +19,7 @@ for s in $STEPS; do
     test)    run 900 pytest bash -c "python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1"; tail -30 gpurun_out/${TAG}_pytest.log ;;
     testall) run 1000 pytest bash -c "python -m pytest tests -m gpu -q --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1"; tail -40 gpurun_out/${TAG}_pytest.log ;;
     bench)   run 400 bench bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err"; cat gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
-    configs) for c in 1 2host 3 4a 4b 5 k2; do run 300 config_$c bash -c "python tools/run_config.py --config $c >> gpurun_out/${TAG}_configs.jsonl 2>> gpurun_out/${TAG}_configs.err"; done; cat gpurun_out/${TAG}_configs.jsonl ;;
+    configs) for c in 1 2host 3 4a 4b 5 k2 mk4 mk8; do run 300 config_$c bash -c "python tools/run_config.py --config $c >> gpurun_out/${TAG}_configs.jsonl 2>> gpurun_out/${TAG}_configs.err"; done; cat gpurun_out/${TAG}_configs.jsonl ;;
     prof2)   run 600 prof2 bash tools/profile.sh ${TAG}_cfg2 > gpurun_out/${TAG}_prof2.log 2>&1; tail -25 gpurun_out/${TAG}_prof2.log ;;
     prof4a)  run 600 prof4a bash tools/profile.sh ${TAG}_cfg4a tools/run_config.py --config 4a > gpurun_out/${TAG}_prof4a.log 2>&1; tail -12 gpurun_out/${TAG}_prof4a.log ;;
     prof4b)  run 600 prof4b bash tools/profile.sh ${TAG}_cfg4b tools/run_config.py --config 4b > gpurun_out/${TAG}_prof4b.log 2>&1; tail -12 gpurun_out/${TAG}_prof4b.log ;;
