@@ -375,6 +375,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 // mod 2^32; rounding margin checked by the oracle test).
 struct MkBrArgs {
     DiagArgs diag;
+    int32_t R;            // rotations in the batch (workgroups of mk_blind_rotate_kernel_w2 hold several: the last one may be padded)
     const int32_t *bara;  // [R][P*n+1]
     const cplx *bk;       // [P][n][2*L*P + 2*L][8][64] spectra (engine order, scaled 1/M)
     int32_t *ext;         // [R][P*N+1]
@@ -668,8 +669,10 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
     if (PARTY == 1) STAMP_FLUSH(P.diag, WV);
 }
 
-template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
+// RW rotations per workgroup advance in lockstep (the barriers are workgroup-wide): rotations that read the same key
+// values at the same time share one trip beyond L2 (the 2-party key is 197 MB as spectra).
+template <int L, bool MARGIN = false, int RW = 2>
+__global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
 {
     static_assert(L % 2 == 0, "the two waves split the digits evenly");
     constexpr int NP = 2;
@@ -677,13 +680,17 @@ __global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                        // [NP+1][N]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [2 waves][kXchElems]
+    const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 1, tid_r = tid & 127;
+    const int rot = tid >> 7;                                                    // rotation within the workgroup
+    constexpr size_t kRotBytes = (NP + 1) * kN * 4 + (2 * kXchElems + kM) * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);      // [NP+1][N]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + (NP + 1) * kN * 4);   // [2 waves][kXchElems]
     cplx *extra = xch_all + 2 * kXchElems;                                       // [512] second hand-off slot of wave 1
-    cplx *tw2_lds = extra + kM;                                                  // [8][8]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);             // [8][8]
     cplx *xch_own = xch_all + wv * kXchElems, *xch_oth = xch_all + (1 - wv) * kXchElems;
-    const size_t w = blockIdx.x;
+    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const bool live = w_raw < (size_t)P.R;                                       // a padding rotation repeats the last one, stores nothing
+    const size_t w = live ? w_raw : (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * (NP * P.n + 1);
     const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
 
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
     if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
     {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
         const int barb = bara[NP * P.n] & (2 * kN - 1);
-        for (int j = tid; j < kN; j += 128) {
+        for (int j = tid_r; j < kN; j += 128) {
             const int idx = (j + barb) & (2 * kN - 1);
             acc_lds[j] = 0;
             acc_lds[kN + j] = 0;
@@ -709,16 +716,17 @@ __global__ __launch_bounds__(128, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
         mk2_party_steps<L, 0, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
         mk2_party_steps<L, 1, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
     }
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    if (!live) return;
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
-    for (int jj = tid; jj < NP * kN; jj += 128) {
+    for (int jj = tid_r; jj < NP * kN; jj += 128) {
         const int c = jj >> 10, j1 = jj & (kN - 1);
         const int32_t v = acc_lds[jj];
         if (j1 == 0) ext[c * kN] = v;
         else ext[c * kN + kN - j1] = (int32_t)(0u - (uint32_t)v);
     }
-    if (tid == 0) ext[NP * kN] = acc_lds[NP * kN];
+    if (tid_r == 0) ext[NP * kN] = acc_lds[NP * kN];
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------

@@ -106,6 +106,7 @@ struct tfhe_ctx {
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
+    int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
@@ -1293,16 +1294,26 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     if (rc) return rc;
     const bool dg = c->measure_margin;
     a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
-    a.n = n; a.mu = (int32_t)(1u << 29);
+    a.n = n; a.mu = (int32_t)(1u << 29); a.R = (int32_t)B;
     const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
     if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
-        const size_t lds2 = (size_t)(NP + 1) * kN * 4 + (2 * kXchElems + kM + 64) * sizeof(cplx);
-#define LAUNCH_MK2(LL)                                                                                             \
-        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, true>), dim3((unsigned)B), dim3(128), lds2, s, a); \
-        else hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, false>), dim3((unsigned)B), dim3(128), lds2, s, a)
-        LAUNCH_MK2(4);
+        // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four)
+        const int rw = c->mk_rw;
+        const size_t lds2 = (size_t)rw * ((NP + 1) * kN * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
+        const unsigned nblk = (unsigned)((B + rw - 1) / rw);
+        a.R = (int32_t)B;
+#define LAUNCH_MK2(LL, DG, RWV)                                                                                    \
+        do {                                                                                                       \
+            if (lds2 > 64 * 1024)                                                                                  \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w2<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+            hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), lds2, s, a);  \
+        } while (0)
+        if (rw == 2 && dg) LAUNCH_MK2(4, true, 2);
+        else if (rw == 2) LAUNCH_MK2(4, false, 2);
+        else if (dg) LAUNCH_MK2(4, true, 1);
+        else LAUNCH_MK2(4, false, 1);
 #undef LAUNCH_MK2
         name_kernel(c, "mk_blind_rotate_kernel_w2<%d>", c->P.bs_l);
     } else if (special) {
@@ -1522,6 +1533,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "n2048_rw")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
         c->n2048_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "mk_rw")) {
+        if (value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_rw must be 1 or 2");
+        c->mk_rw = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_variant")) {
