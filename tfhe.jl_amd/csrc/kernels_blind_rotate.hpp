@@ -737,6 +737,7 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
 // (:371-376, :382-385).
 struct MkGenArgs {
     DiagArgs diag;
+    int32_t R;            // rotations in the batch (a workgroup holds RW of them: the last one may be padded)
     const int32_t *bara;  // [R][P*n+1]
     const cplx *bk;       // [P][n][2*L*P + 2*L][8][64]
     int32_t *ext;         // [R][P*N+1]
@@ -745,19 +746,25 @@ struct MkGenArgs {
     int32_t n, mu, parties, L;
 };
 
-template <bool MARGIN = false>
-__global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArgs P)
+// RW rotations (one wave each) per workgroup, kept in lockstep by one barrier per CMUX step: the 4- and 8-party keys are
+// 0.8 and 4.7 GB as spectra (1.15 MB per step at 8 parties), far beyond L2 and the Infinity Cache, and rotations that
+// read the same key values at the same time share one trip to HBM.  Nothing is exchanged between the waves.
+template <bool MARGIN = false, int RW = 1>
+__global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkGenArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NP = P.parties, L = P.L;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + (size_t)(NP + 1) * kN * 4);
+    const int lane = threadIdx.x & 63, rot = threadIdx.x >> 6;
+    const size_t rot_bytes = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * rot_bytes);  // [NP+1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + rot * rot_bytes + (size_t)(NP + 1) * kN * 4);
     cplx *tw2_lds = xch + kXchElems;
-    const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
+    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const bool live = w_raw < (size_t)P.R;                                   // a padding rotation repeats the last one, stores nothing
+    const size_t w = live ? w_raw : (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * ((size_t)NP * P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
@@ -841,8 +848,10 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
             finish(o_party, party);
             finish(o_body, NP);
             WAVE_LDS_FENCE();
+            if (RW > 1) __syncthreads();     // lockstep only: the workgroup's rotations share their key fetches
         }
     }
+    if (!live) return;
 
     int32_t *ext = P.ext + w * ((size_t)NP * kN + 1);
     for (int c = 0; c < NP; c++)
@@ -854,7 +863,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel_general(MkGenArg
             else ext[(size_t)c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
         }
     if (lane == 0) ext[(size_t)NP * kN] = acc_lds[NP * kN];
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, lane == 0);
 }
 
 // ---- small batches: two waves per blind rotation ----------------------------------------------------

@@ -106,6 +106,7 @@ struct tfhe_ctx {
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
+    int mkg_rw = 0;                // any-party kernel: cap on the rotations per workgroup (0: as many as fit, at most 4)
     int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
@@ -1329,13 +1330,29 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
     } else {
         MkGenArgs ga;
-        ga.diag = a.diag; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
-        if (lds > 64 * 1024) {
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
+        // the kernel needs a whole SIMD's registers, so a CU holds four waves whatever the grouping: as many rotations per
+        // workgroup (in lockstep, sharing their key fetches) as fit in LDS, four at most
+        int rw = (int)std::min<size_t>(4, (160 * 1024) / lds);
+        if (c->mkg_rw > 0) rw = std::min(rw, c->mkg_rw);
+        if (B < 2) rw = 1;
+        const size_t ldsg = (size_t)rw * lds;
+        const unsigned nblk = (unsigned)((B + rw - 1) / rw);
+#define LAUNCH_MKG(DG, RWV)                                                                                        \
+        do {                                                                                                       \
+            if (ldsg > 64 * 1024)                                                                                  \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
+            hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
+        } while (0)
+#define LAUNCH_MKG_RW(RWV) do { if (dg) LAUNCH_MKG(true, RWV); else LAUNCH_MKG(false, RWV); } while (0)
+        switch (rw) {
+        case 4: LAUNCH_MKG_RW(4); break;
+        case 3: LAUNCH_MKG_RW(3); break;
+        case 2: LAUNCH_MKG_RW(2); break;
+        default: LAUNCH_MKG_RW(1); break;
         }
-        if (dg) hipLaunchKernelGGL(mk_blind_rotate_kernel_general<true>, dim3((unsigned)B), dim3(64), lds, s, ga);
-        else hipLaunchKernelGGL(mk_blind_rotate_kernel_general<false>, dim3((unsigned)B), dim3(64), lds, s, ga);
+#undef LAUNCH_MKG_RW
+#undef LAUNCH_MKG
         name_kernel(c, "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
     }
     HIP_TRY(c, hipGetLastError());
@@ -1533,6 +1550,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "n2048_rw")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
         c->n2048_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "mkg_rw")) {
+        if (value < 0 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_rw must be 0..4");
+        c->mkg_rw = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_rw")) {
