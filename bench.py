@@ -126,12 +126,21 @@ def main():
     # own private stream), and torch's copies and the RCCL gather order themselves against torch's CURRENT stream.
     work_stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(work_stream)
-    if world > 1:
+    # TFHE_BENCH_FORCE_DIST=1: a single rank still goes through the process group (RCCL init, barrier, max-reduce and the
+    # gather with one participant) — the only way to execute those calls on a one-GPU box (tests/test_bench_contract.py)
+    use_dist = (world > 1 or os.environ.get("TFHE_BENCH_FORCE_DIST") == "1") and not args.fanout
+    if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        tmo = datetime.timedelta(seconds=300)          # a rank that died must not leave the others waiting for half an hour
         if share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
 
     # --- keys: identical on every rank (seed 123), replicated per GPU ------------------------------
     params = tfhe.tfhe_parameters_80() if args.params == "80" else tfhe.tfhe_parameters_128()
@@ -171,7 +180,7 @@ def main():
         total_per_step = BT
         irng = np.random.default_rng(456 + rank)
     hx, hy, hz = (tfhe.encrypt(irng, sk, b).data for b in (bx, by, bz))
-    use_gather = world > 1 and not args.no_gather
+    use_gather = use_dist and not args.no_gather
     if not args.fanout:
         dx, dy, dz = (torch.from_numpy(h).to(dev) for h in (hx, hy, hz))
         # two result buffers: the gather of step i (a point-to-point transfer to rank 0 over xGMI) overlaps step i + 1
@@ -197,6 +206,21 @@ def main():
                           for _ in range(2)]
             self.full = None
             self.pending = [None, None]
+            # one complete gather now (untimed): an asynchronous collective reports a backend problem at wait(), not at the
+            # call, so find out before the timed loop which transport works
+            for mode in ("gather", "all_gather"):
+                self.mode = mode
+                try:
+                    self.launch(0, self.padded[1][:B])
+                    self.wait(0)
+                    if not share_gpu:
+                        torch.cuda.synchronize(dev)
+                    break
+                except (RuntimeError, NotImplementedError) as e:
+                    print(f"bench.py: rank {rank}: {mode} to rank 0 failed ({e})", file=sys.stderr)
+                    self.pending[0] = None
+            else:
+                sys.exit("bench.py: neither gather nor all_gather works on this process group")
 
         def wait(self, k):
             if self.pending[k] is not None:
@@ -213,12 +237,8 @@ def main():
                 self.padded[k][:B].copy_(src)
                 send = self.padded[k]
             if self.mode == "gather":
-                try:
-                    self.pending[k] = dist.gather(send, self.parts[k], dst=0, async_op=True)
-                    return
-                except (RuntimeError, NotImplementedError) as e:   # backend without gather: fall back, loudly
-                    print(f"bench.py: dist.gather unavailable ({e}); using all_gather", file=sys.stderr)
-                    self.mode = "all_gather"
+                self.pending[k] = dist.gather(send, self.parts[k], dst=0, async_op=True)
+                return
             if self.full is None:
                 self.full = [torch.empty((world * self.longest, n1), dtype=torch.int32, device=send.device) for _ in range(2)]
             self.pending[k] = dist.all_gather_into_tensor(self.full[k], send, async_op=True)
@@ -257,7 +277,7 @@ def main():
             gatherer.wait(1)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -273,7 +293,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
     kernel_name = eng.last_kernel_name()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -353,7 +373,7 @@ def main():
                 "gates_per_gpu_per_step": args.gates if args.workload == "nand" else B,
                 "inputs": "host buffers (PCIe inside the timed region)" if args.fanout else "resident in HBM",
                 "launch": ("one process, multi-device context (tfhe_ctx_create_multi)" if args.fanout else
-                           "one process per GPU (torch.distributed)" if world > 1 else "one process"),
+                           "one process per GPU (torch.distributed)" if use_dist else "one process"),
                 "result_gather": ("none (results written into the caller's host buffer)" if args.fanout else
                                   (("gloo " if share_gpu else "rccl ") + (gatherer.mode if gatherer else "gather") + " to rank 0, overlapped with the next step"
                                    + (" (one-GPU rehearsal)" if share_gpu else "")) if use_gather else "none"),
@@ -399,7 +419,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline and args.workload == "nand" and not args.fanout:
             result["cpu_baseline"] = cpu_baseline(tfhe, params, ck, hx, hy, out, args)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ck.close()

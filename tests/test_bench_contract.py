@@ -95,3 +95,16 @@ def test_bench_fanout_context():
     assert d["n_gpus"] == 2 and d["outputs_decrypt_correctly"] is True and "multi-device context" in d["config"]["launch"]
     assert d["roofline"]["units_per_launch"] == 600 and "host buffers" in d["config"]["inputs"]
     assert abs(d["value"] - 600 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_through_rccl():
+    """TFHE_BENCH_FORCE_DIST=1: one rank, but the barrier, the max-reduce of the elapsed time and the result gather go
+    through the RCCL process group (the only way to execute bench.py's RCCL calls on a one-GPU box)."""
+    env = dict(os.environ, TFHE_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFHE_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gates", "300",
+                        "--no-cpu-baseline", "--no-diagnostics"], env)
+    assert d["n_gpus"] == 1 and d["outputs_decrypt_correctly"] is True and d["gather_matches_local_shard"] is True
+    assert d["config"]["result_gather"].startswith("rccl gather to rank 0")

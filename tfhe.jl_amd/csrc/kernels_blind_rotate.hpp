@@ -385,6 +385,30 @@ struct MkBrArgs {
     int32_t mu;
 };
 
+// `mid()` runs between the store and the load of the second transposition, when x[] is dead: the place to request global
+// data (32 registers are free there) that the caller needs right after the transform.
+template <typename MID>
+__device__ __forceinline__ void fft_fwd_wave_mid(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch, MID &&mid)
+{
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+    x1_store_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_b(lane, x, xch);
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    WAVE_LDS_FENCE();
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    mid();
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+    WAVE_LDS_FENCE();
+    dft8<false>(x);
+}
+
 __device__ __forceinline__ void fft_fwd_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
 {
     dft8<false>(x);
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 // digits of the other mask; wave 1: every digit of the body and the other half) and multiply them into their own
 // partial sums of the three new polynomials (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
 // wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
-// polynomials.  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
+// polynomials.  Two barriers per step (hand-off written / accumulator updated).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
 // reuses the transposition buffers).  Same words as mk_blind_rotate_kernel.  L must be even.
 template <int L, int PARTY, int WV, bool MARGIN>
 __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
@@ -564,6 +588,10 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
     constexpr int NP = 2;
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
     constexpr int OTHER = 1 - PARTY;
+#ifndef TFHE_MK_KPN
+#define TFHE_MK_KPN 2
+#endif
+    constexpr int MKPN = TFHE_MK_KPN;
     const int beta = P.g.log2_base;
     int a_next = bara[PARTY * P.n] & (2 * kN - 1);
     STAMP_DECL;
@@ -610,11 +638,15 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
                 for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_party[k2 * 64];
                 cplx x[8];
                 load_digits2(temp, p + 1, beta, x);
-                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch_own);
-                STAMP(1);
                 cplx kbo[8];
+                // (the first values of the second poly are requested inside the transform, where x[] is dead: see blind_rotate_kernel_n2048)
+                fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch_own, [&]() {
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
+                    for (int k2 = 0; k2 < MKPN; k2++) kbo[k2] = k_body[k2 * 64];
+                });
+                STAMP(1);
+#pragma unroll
+                for (int k2 = MKPN; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kpa[k2], out[PARTY][k2]);
                 if (s == OTHER) {
@@ -650,10 +682,13 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
             for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cadd(out[NP][k2], xch_oth[k2 * 64 + lane]);
         }
         STAMP(5);
-        __syncthreads();      // both have read: the transposition buffers are their owners' again
+        // No barrier here: the inverse transforms run in the OTHER wave's transposition buffer, the one this wave has just
+        // read (a wave's LDS operations execute in order) and that its owner does not touch again before the barrier that
+        // ends the step; this wave's own buffer may still be being read by the other wave.
+        WAVE_LDS_FENCE();
         STAMP(6);
         auto finish = [&](cplx (&o)[8], int d) {
-            fft_inv_wave(lane, o, tw1f, tw2_lds, xch_own);
+            fft_inv_wave(lane, o, tw1f, tw2_lds, xch_oth);
             int32_t accr[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
@@ -1351,8 +1386,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 // M = 1024 folded points.  One radix-2 DIF stage is split across the two waves of a 128-thread block:
 //   a_j = z_j + z_{j+512}  -> wave 0 -> even frequencies,   b_j = (z_j - z_{j+512}) W_1024^j -> wave 1 -> odd,
 // then each wave runs the same 512-point transform as the N = 1024 kernels on its half, MACs its own
-// frequencies, inverse-transforms them, and the halves are recombined through LDS (2 barriers per inverse
-// transform).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
+// frequencies and inverse-transforms them; then wave 0 recombines output polynomial 0 and wave 1 polynomial 1 (one
+// 8 KB hand-off each way, two barriers per step).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
 //   wave 0 pass-A input  x_r = e^{-i pi r/32}  (u + kappa u'),   lane factor w^t             in tw1f
 //   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
 // Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
@@ -1420,6 +1455,11 @@ template <int L, bool MARGIN = false, int RW = 2>
 __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel_n2048(Br2048Args P)
 {
     constexpr int K1 = 2;
+#ifndef TFHE_N2048_KPN
+#define TFHE_N2048_KPN 2      // measured on one device, 4096 rotations of config 4b: 0: 54.2 ms, 1: 49.8, 2: 48.0, 3: 49.9, 4: 49.3-50.1, 6: 48.6-49.2, 8: 49.4-50.4
+#endif
+    constexpr int KPN = TFHE_N2048_KPN;      // co = 0 key values requested inside the transform (0: all after it)
+    constexpr bool KPRE = KPN > 0;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
@@ -1486,60 +1526,90 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
                     x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
                 });
                 STAMP(1);
-                fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
-                STAMP(2);
-                // (requesting the co = 0 chunk before the FFT, as the N = 1024 kernels do, costs 32 more live registers
-                //  here: with temp[32] live across the transform that spills into the loop and is slower, measured)
+                // the first KPN values of the co = 0 key chunk are requested inside the transform, between the store and the load
+                // of its second transposition (x[] is dead there; a chunk requested before the transform spills into the
+                // loop: 71.7 ms), the rest after the transform: the L2 round trip then overlaps the last radix-8 pass
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
+                cplx kv0[8];
+                if (KPRE) {
+                    fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch, [&]() {
 #pragma unroll
-                for (int co = 0; co < K1; co++) {
-                    cplx kv[8];
+                        for (int k2 = 0; k2 < KPN; k2++) kv0[k2] = kp[k2 * 64];
+                    });
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)co * 2 * kM + k2 * 64];
+                    for (int k2 = KPN; k2 < 8; k2++) kv0[k2] = kp[k2 * 64];
+                } else {
+                    fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
+                }
+                STAMP(2);
+                {
+                    cplx kv1[8];
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kv[k2], out[co][k2]);
+                    for (int k2 = 0; k2 < 8; k2++) kv1[k2] = kp[(size_t)2 * kM + k2 * 64];
+                    if (!KPRE) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) kv0[k2] = kp[k2 * 64];
+                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kv0[k2], out[0][k2]);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], kv1[k2], out[1][k2]);
                 }
                 STAMP(3);
             }
         }
-        __syncthreads();   // every rotated read of this step is done before anybody updates acc_lds
         STAMP(4);
+        // Both inverse half-transforms first (wave 0 then holds alpha_0, alpha_1, wave 1 beta_0, beta_1); wave 0 finishes
+        // output polynomial 0 and wave 1 polynomial 1, all four coefficient classes of it, so each wave hands over ONE
+        // block (wave 0: alpha_1, wave 1: beta_0) and a step has two barriers: the one before the hand-off is read (every
+        // rotated read of this step precedes it in every wave, so it also covers the accumulator update) and the one
+        // that ends the step.
+        fft_inv_wave(lane, out[0], tw1f, tw2_lds, xch);
+        fft_inv_wave(lane, out[1], tw1f, tw2_lds, xch);
+        STAMP(5);
+        WAVE_LDS_FENCE();
+        if (wave1) {           // (wave-uniform branches, not selects: a select would copy the block into new registers)
 #pragma unroll
-        for (int d = 0; d < K1; d++) {
-            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);          // alpha (wave 0) / beta (wave 1)
-            STAMP(5);
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[0][r];
+        } else {
 #pragma unroll
-            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[d][r];
-            __syncthreads();
-            STAMP(6);
-            cplx oth[8];
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[1][r];
+        }
+        __syncthreads();
+        STAMP(6);
+        cplx oth[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
-            __syncthreads();
-            STAMP(7);
-            // wave 0: (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024
-            // wave 1: (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
+        for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+        STAMP(7);
+        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) {
             static_for<0, 8>([&](auto rc) {
                 constexpr int R = decltype(rc)::value;
-                const cplx al = wave1 ? oth[R] : out[d][R], be = wave1 ? out[d][R] : oth[R];
+                const cplx al = alpha[R], be = beta[R];
                 const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
                 const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er;    // conj(beta) e_r
-                const double vr = wave1 ? al.x - br : al.x + br;                        // conj(alpha) = (al.x, -al.y)
-                const double vi = wave1 ? -al.y - bi : -al.y + bi;
-                const double cr = wave1 ? cos_pi32(R + 8) : cos_pi32(R), ci = wave1 ? -sin_pi32(R + 8) : -sin_pi32(R);
-                const double re = vr * cr - vi * ci, im = vr * ci + vi * cr;
+                // (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024        conj(alpha) = (al.x, -al.y)
+                // (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
+                const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
+                const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
+                const double re0 = pr * c0r - pi * c0i, im0 = pr * c0i + pi * c0r;
+                const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
                 if (MARGIN) {
-                    const double fa = frac_dist(re), fb = frac_dist(im);
-                    worst = fa > worst ? fa : worst;
-                    worst = fb > worst ? fb : worst;
+                    const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
+                    worst = f0 > worst ? f0 : worst;
+                    worst = f1 > worst ? f1 : worst;
+                    worst = f2 > worst ? f2 : worst;
+                    worst = f3 > worst ? f3 : worst;
                 }
-                const int jlo = lane + 64 * R + (wave1 ? 512 : 0);
-                int32_t *ap = acc_lds + d * kN2;
-                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re));
-                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im));
+                const int jlo = lane + 64 * R;
+                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
+                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
+                ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
+                ap[jlo + 1536] = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
             });
-            STAMP(8);
-        }
+        };
+        if (wave1) finish(oth, out[1], acc_lds + kN2);
+        else finish(out[0], oth, acc_lds);
+        STAMP(8);
         __syncthreads();
         STAMP(9);
     }
