@@ -161,7 +161,7 @@ def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
     x, y = _words(rng, 4, w), _words(rng, 4, w)[::-1].copy()
     x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
     y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
-    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_general(P={parties},L={l})")
+    _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_general(P={parties},L={l}" + (",acc=global)" if parties > 4 else ")"))
     ck.close()
 
 

@@ -121,10 +121,18 @@ def test_mk_gpu_parity_many_parties(orc, tfhe, which, parties, n):
     if parties == 2:
         special = eng.mk_gate_nand(x, y)
         eng.set_option("mk_general", 1)
+    want = o.mk_gate_nand(x, y, nthreads=5)
     got = eng.mk_gate_nand(x, y)
-    assert np.array_equal(got, o.mk_gate_nand(x, y, nthreads=5))
+    assert np.array_equal(got, want)
+    assert ("acc=global" in eng.last_kernel_name()) == (parties > 4)      # default placement of the accumulators
     if parties == 2:
         assert np.array_equal(got, special)
+    # both placements of the accumulator polynomials (LDS / global memory), with and without lockstep groups
+    for acc, rw in ((1, 0), (0, 0), (1, 1), (0, 1)):
+        eng.set_option("mkg_acc", acc)
+        eng.set_option("mkg_rw", rw)
+        assert np.array_equal(eng.mk_gate_nand(x, y), want), (acc, rw)
+        assert ("acc=global" in eng.last_kernel_name()) == bool(acc)
     ck.close()
 
 

@@ -779,12 +779,17 @@ struct MkGenArgs {
     Tables T;
     Gadget g;
     int32_t n, mu, parties, L;
+    int32_t *acc;         // ACCG only: [rotations rounded up to the workgroup size][P+1][N] accumulators in global memory
 };
 
 // RW rotations (one wave each) per workgroup, kept in lockstep by one barrier per CMUX step: the 4- and 8-party keys are
 // 0.8 and 4.7 GB as spectra (1.15 MB per step at 8 parties), far beyond L2 and the Infinity Cache, and rotations that
 // read the same key values at the same time share one trip to HBM.  Nothing is exchanged between the waves.
-template <bool MARGIN = false, int RW = 1>
+// ACCG: the accumulator (P + 1 polynomials, 36 KB at 8 parties) lives in global memory instead of LDS, so that LDS (10 KB
+// per wave) no longer limits a CU to 3 rotations at 8 parties / 5 at 4: the accumulator traffic (two reads and one write
+// of every polynomial per step, L2-resident) is a tenth of the step's key traffic.  A wave reads back only what it wrote
+// itself; the workgroup-scope fence at the end of a step orders those stores before the next step's loads.
+template <bool MARGIN = false, int RW = 1, bool ACCG = false>
 __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkGenArgs P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -793,11 +798,12 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     const int lane = threadIdx.x & 63, rot = threadIdx.x >> 6;
-    const size_t rot_bytes = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * rot_bytes);  // [NP+1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + rot * rot_bytes + (size_t)(NP + 1) * kN * 4);
-    cplx *tw2_lds = xch + kXchElems;
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const size_t rot_bytes = (ACCG ? 0 : (size_t)(NP + 1) * kN * 4) + (kXchElems + 64) * sizeof(cplx);
+    int32_t *acc_lds = ACCG ? P.acc + w_raw * (size_t)(NP + 1) * kN                  // [NP+1][N] (the name stays: LDS in the default build)
+                            : reinterpret_cast<int32_t *>(smem + rot * rot_bytes);
+    cplx *xch = reinterpret_cast<cplx *>(smem + rot * rot_bytes + (ACCG ? 0 : (size_t)(NP + 1) * kN * 4));
+    cplx *tw2_lds = xch + kXchElems;
     const bool live = w_raw < (size_t)P.R;                                   // a padding rotation repeats the last one, stores nothing
     const size_t w = live ? w_raw : (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * ((size_t)NP * P.n + 1);
@@ -820,7 +826,15 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
             acc_lds[NP * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
         }
     }
-    WAVE_LDS_FENCE();
+    auto acc_fence = [&]() {
+        if (ACCG) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            WAVE_LDS_FENCE();
+        }
+    };
+    acc_fence();
 
     auto finish = [&](cplx (&o)[8], int d) {      // inverse transform, round, add into accumulator polynomial d
         fft_inv_wave(lane, o, tw1f, tw2_lds, xch);
@@ -857,7 +871,10 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
                 for (int p = 0; p < L; p++) {
                     const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]
                     const cplx *k_body = key + (size_t)(is_body ? 2 * L * NP + p : p * NP + s) * kM;                 // c0[p] | x[p, s]
-                    cplx kpa[8], kbo[8];                      // requested before the FFT (see mk_party_steps)
+                    // One wave per SIMD (a whole SIMD's registers, the surplus used as spill space): the two key polys every
+                    // source needs are requested before the transform, the third after it.  (At two waves per SIMD with 256
+                    // registers the kernel spills to scratch inside the transform loop: 3x slower, measured.)
+                    cplx kpa[8], kbo[8];
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) { kpa[k2] = k_party[k2 * 64]; kbo[k2] = k_body[k2 * 64]; }
                     cplx x[8];
@@ -882,7 +899,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
             }
             finish(o_party, party);
             finish(o_body, NP);
-            WAVE_LDS_FENCE();
+            acc_fence();
             if (RW > 1) __syncthreads();     // lockstep only: the workgroup's rotations share their key fetches
         }
     }

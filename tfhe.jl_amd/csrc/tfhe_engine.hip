@@ -102,11 +102,12 @@ struct tfhe_ctx {
     int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
-    DevBuf bara, ext, map, io[4], diag, abar;
+    DevBuf bara, ext, map, io[4], diag, abar, mk_acc;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
     int mkg_rw = 0;                // any-party kernel: cap on the rotations per workgroup (0: as many as fit, at most 4)
+    int mkg_acc = -1;              // any-party kernel: accumulators in LDS (0) / in global memory (1) / by party count (-1: global above 4 parties)
     int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
@@ -307,7 +308,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
-    c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release();
+    c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release(); c->mk_acc.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1333,16 +1334,25 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
         // the kernel needs a whole SIMD's registers, so a CU holds four waves whatever the grouping: as many rotations per
         // workgroup (in lockstep, sharing their key fetches) as fit in LDS, four at most
-        int rw = (int)std::min<size_t>(4, (160 * 1024) / lds);
+        // accumulators in global memory: LDS holds only the transposition buffer, eight waves fit a CU whatever P is
+        const bool accg = c->mkg_acc < 0 ? NP > 4 : c->mkg_acc != 0;
+        const size_t lds_rot = accg ? (kXchElems + 64) * sizeof(cplx) : lds;
+        int rw = (int)std::min<size_t>(4, (160 * 1024) / lds_rot);
         if (c->mkg_rw > 0) rw = std::min(rw, c->mkg_rw);
         if (B < 2) rw = 1;
-        const size_t ldsg = (size_t)rw * lds;
+        const size_t ldsg = (size_t)rw * lds_rot;
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
+        ga.acc = nullptr;
+        if (accg) {
+            HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kN * sizeof(int32_t)));
+            ga.acc = (int32_t *)c->mk_acc.p;
+        }
 #define LAUNCH_MKG(DG, RWV)                                                                                        \
         do {                                                                                                       \
             if (ldsg > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
-            hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<DG, RWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
+            if (accg) hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, true>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
+            else hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, false>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
         } while (0)
 #define LAUNCH_MKG_RW(RWV) do { if (dg) LAUNCH_MKG(true, RWV); else LAUNCH_MKG(false, RWV); } while (0)
         switch (rw) {
@@ -1353,7 +1363,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         }
 #undef LAUNCH_MKG_RW
 #undef LAUNCH_MKG
-        name_kernel(c, "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
+        name_kernel(c, accg ? "mk_blind_rotate_kernel_general(P=%d,L=%d,acc=global)" : "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -1550,6 +1560,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "n2048_rw")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
         c->n2048_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "mkg_acc")) {
+        if (value < -1 || value > 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_acc must be -1 (by party count), 0 (LDS) or 1 (global memory)");
+        c->mkg_acc = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "mkg_rw")) {
