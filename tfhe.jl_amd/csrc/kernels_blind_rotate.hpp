@@ -865,7 +865,9 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
                     int32_t cur[16];
 #pragma unroll
                     for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
-                    rotate_sub2(lane, a, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
+                    int a_here = a;
+                    asm volatile("" : "+v"(a_here));   // keeps the 32 rotate addresses / signs from being hoisted out of the source loop
+                    rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
                 }
 #pragma unroll 1
                 for (int p = 0; p < L; p++) {
