@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 2
+#define TFHE_MI355X_ABI_VERSION 3
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -135,6 +135,17 @@ int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra);
 
 /* KeyswitchKey (keyswitch.jl:7-42), Int32 [kN][t][base-1][n+1]. */
 int32_t tfhe_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks);
+
+/* Generates the cloud key ON THE DEVICE and loads it: BootstrapKey = tgsw_encrypt(s_i) for every bit of the LWE key
+ * (bootstrap.jl:6-15, tgsw.jl:52-88, tlwe.jl:63-73) and KeyswitchKey (keyswitch.jl:14-41, lwe.jl:49-55) — the work
+ * CloudKey(rng, secret_key) does on the host (api.jl:111-127).  lwe_key: [n] words 0/1 (SecretKey.key, lwe.jl:11-17);
+ * tlwe_key: [k][N] words 0/1 (TLweKey, tlwe.jl:11-21); the noise parameters are bs_noise_stddev / ks_noise_stddev of
+ * SchemeParameters (api.jl:4-21).  Randomness is Philox4x32-10 keyed by `seed` (csrc/kernels_keygen.hpp documents the
+ * streams; the reference's MersenneTwister stream is not reproduced).  bk_out / ks_out (either may be NULL) receive the
+ * canonical Int32 arrays, [n][l][k+1][k+1][N] and [kN][t][base-1][n+1], e.g. to serialise the key.
+ * Single-key contexts; a multi-device context generates on its first device and replicates. */
+int32_t tfhe_keygen_cloud_key(tfhe_ctx *ctx, const int32_t *lwe_key, const int32_t *tlwe_key, double bs_noise_stddev,
+                              double ks_noise_stddev, uint64_t seed, int32_t *bk_out, int32_t *ks_out);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 

@@ -20,7 +20,8 @@
 module TFHEMI355X
 
 using TFHE
-using TFHE: LweSample, LweParams, CloudKey, SchemeParameters, MKCloudKey, MKLweSample
+using TFHE: LweSample, LweParams, CloudKey, SecretKey, SchemeParameters, MKCloudKey, MKLweSample
+using Random: AbstractRNG
 
 export GpuCloudKey, GpuMKCloudKey, gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not, gate_constant,
        gate_nor, gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux, gates_batch, mk_gate_nand
@@ -98,6 +99,23 @@ mutable struct GpuCloudKey
         flat = flatten_keyswitch_key(ck.keyswitch_key, p.lwe_size)
         GC.@preserve flat check(ctx, ccall((:tfhe_load_keyswitch_key, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Int32}), ctx, flat))
+        gck = new(p, ctx)
+        finalizer(g -> ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx), gck)
+        gck
+    end
+
+    # The cloud key generated ON THE GPU (tfhe_keygen_cloud_key) instead of by CloudKey(rng, secret_key) on the host
+    # (api.jl:111-127): the TLWE key bits and a 64-bit seed come from `rng`, the bootstrap and keyswitch keys never
+    # exist on the host.  The key material follows the library's Philox streams, not MersenneTwister's.
+    function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing)
+        p = secret_key.params
+        ctx = create_context(p, devices === nothing ? [device] : devices)
+        lwe_bits = Int32.(secret_key.key.key)                                        # lwe.jl:11-17
+        tlwe_bits = Int32.(rand(rng, Bool, p.tlwe_polynomial_degree, p.tlwe_mask_size))   # [N, k] = C-order [k][N]; tlwe.jl:15-20
+        seed = rand(rng, UInt64)
+        GC.@preserve lwe_bits tlwe_bits check(ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, UInt64, Ptr{Int32}, Ptr{Int32}),
+            ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
         gck = new(p, ctx)
         finalizer(g -> ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx), gck)
         gck

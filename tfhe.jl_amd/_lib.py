@@ -20,9 +20,9 @@ ABI_SYMBOLS = [
     "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
-    "tfhe_mk_expand_load_bootstrap_key",
+    "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -64,6 +64,7 @@ def load():
     lib.tfhe_load_bootstrap_key_i32.argtypes = [vp, vp]
     lib.tfhe_load_bootstrap_key_c128.argtypes = [vp, vp]
     lib.tfhe_load_keyswitch_key.argtypes = [vp, vp]
+    lib.tfhe_keygen_cloud_key.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_uint64, vp, vp]
     lib.tfhe_gates_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.tfhe_gates_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
     lib.tfhe_bootstrap_batch.argtypes = [vp, i32, vp, vp, i64, i32]
@@ -177,6 +178,21 @@ class Engine:
         if ks.size != want:
             raise ValueError(f"keyswitch key has {ks.size} words, expected {want}")
         self._check(self._lib.tfhe_load_keyswitch_key(self._h, _ptr(ks)))
+
+    def keygen_cloud_key(self, lwe_key, tlwe_key, bs_noise_stddev, ks_noise_stddev, seed, want_arrays=True):
+        """Generates bootstrap + keyswitch key on the device and loads them (tfhe_keygen_cloud_key).  Returns the
+        canonical Int32 arrays (bk [n][l][k+1][k+1][N], ks [kN][t][base-1][n+1]) unless want_arrays is False."""
+        lwe_key, tlwe_key = _i32c(lwe_key), _i32c(tlwe_key)
+        p = self.params
+        if lwe_key.size != self.n or tlwe_key.size != self.k * self.N:
+            raise ValueError(f"secret keys have {lwe_key.size} / {tlwe_key.size} words, expected {self.n} / {self.k * self.N}")
+        bk = ks = None
+        if want_arrays:
+            bk = np.empty((self.n, p.bs_decomp_length, self.k + 1, self.k + 1, self.N), np.int32)
+            ks = np.empty((self.k * self.N, p.ks_decomp_length, (1 << p.ks_log2_base) - 1, self.n + 1), np.int32)
+        self._check(self._lib.tfhe_keygen_cloud_key(self._h, _ptr(lwe_key), _ptr(tlwe_key), float(bs_noise_stddev),
+                                                    float(ks_noise_stddev), int(seed) & (2**64 - 1), _ptr(bk), _ptr(ks)))
+        return bk, ks
 
     # ---- hot path, host buffers ----
     def gates(self, opcodes, in0, in1=None, in2=None):

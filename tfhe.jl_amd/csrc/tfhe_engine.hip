@@ -35,6 +35,7 @@ using namespace tfhe;
 #include "kernels_gates.hpp"
 #include "kernels_blind_rotate.hpp"
 #include "kernels_keyswitch.hpp"
+#include "kernels_keygen.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -389,7 +390,7 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     HIP_TRY(c, hipMalloc((void **)&c->d_bk, npolys * (size_t)(c->P.N / 2) * sizeof(cplx)));
     void *d_in = nullptr;
     HIP_TRY(c, hipMalloc(&d_in, bytes_in));
-    hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyDefault, c->stream)   /* host pointer, or a device buffer (tfhe_keygen_cloud_key) */;
     if (e == hipSuccess) {
         if (big && is_c128)
             hipLaunchKernelGGL(bk_permute_c128_kernel_n2048, dim3((unsigned)npolys), dim3(128), 0, c->stream, (const cplx *)d_in, c->d_bk);
@@ -455,7 +456,7 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     HIP_TRY(c, hipMalloc((void **)&d_canon, bytes));
     const int mode = pick_ks_mode(c);
     auto body = [&]() -> int32_t {
-        HIP_TRY(c, hipMemcpy(d_canon, ks, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_canon, ks, bytes, hipMemcpyDefault));          // host pointer, or a device buffer (tfhe_keygen_cloud_key)
         if (mode == 3) {   // row-padded copy: stride = n+1 rounded up to 4 words so that rows are 16-byte aligned
             const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
             const size_t rows = ks_word_count(c->P) / n1;
@@ -482,6 +483,59 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     c->ks_mode = mode;
     c->have_ks = true;
     return TFHE_OK;
+}
+
+// Generates the cloud key on the device (kernels_keygen.hpp) and loads it: the analogue of CloudKey(rng, secret_key)
+// (api.jl:111-127) with the secret material supplied by the caller.  Optionally copies the canonical Int32 arrays back.
+int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t *tlwe_key, double bs_noise_stddev,
+                              double ks_noise_stddev, uint64_t seed, int32_t *bk_out, int32_t *ks_out)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (!lwe_key || !tlwe_key) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: NULL key pointer");
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "keygen_cloud_key: context is multi-key (use tfhe_mk_expand_load_bootstrap_key)");
+    if (!(bs_noise_stddev >= 0.0) || !(ks_noise_stddev >= 0.0)) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: negative noise parameter");
+    tfhe_ctx *g = c->multi() ? c->kids[0] : c;             // a fan-out context generates on its first device
+    HIP_TRY(c, hipSetDevice(g->device));
+    const tfhe_params &P = c->P;
+    const size_t bk_words = bk_poly_count(P) * (size_t)P.N, ks_words = ks_word_count(P);
+    const size_t Q = ks_words / (size_t)(P.n + 1), kN = (size_t)P.k * P.N;
+    int32_t *d_lwe = nullptr, *d_tlwe = nullptr, *d_bk = nullptr, *d_ks = nullptr;
+    double *d_noise = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_lwe); (void)hipFree(d_tlwe); (void)hipFree(d_bk); (void)hipFree(d_ks); (void)hipFree(d_noise);
+    };
+    auto body = [&]() -> int32_t {
+        HIP_TRY(c, hipMalloc((void **)&d_lwe, (size_t)P.n * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_tlwe, kN * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_bk, bk_words * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_ks, ks_words * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_noise, (Q + 1) * sizeof(double)));
+        HIP_TRY(c, hipMemcpyAsync(d_lwe, lwe_key, (size_t)P.n * 4, hipMemcpyHostToDevice, g->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_tlwe, tlwe_key, kN * 4, hipMemcpyHostToDevice, g->stream));
+        keygen::Args A;
+        A.lwe_key = d_lwe; A.tlwe_key = d_tlwe; A.bk = d_bk; A.ks = d_ks; A.ks_noise = d_noise; A.ks_mean = d_noise + Q;
+        A.n = P.n; A.N = P.N; A.k = P.k; A.l = P.bs_l; A.beta = P.bs_log2_base; A.t = P.ks_t; A.ks_log2_base = P.ks_log2_base;
+        A.bs_alpha = bs_noise_stddev; A.ks_alpha = ks_noise_stddev;
+        A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
+        const size_t samples = (size_t)P.n * P.bs_l * (P.k + 1);
+        const size_t lds = kN * 4 + (size_t)P.k * (P.N / 32) * 4;
+        hipLaunchKernelGGL(keygen::bk_kernel, dim3((unsigned)samples), dim3(256), lds, g->stream, A);
+        hipLaunchKernelGGL(keygen::ks_noise_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, g->stream, A, Q);
+        hipLaunchKernelGGL(keygen::ks_mean_kernel, dim3(1), dim3(256), 0, g->stream, A, Q);
+        hipLaunchKernelGGL(keygen::ks_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, g->stream, A, Q);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(g->stream));
+        if (bk_out) HIP_TRY(c, hipMemcpy(bk_out, d_bk, bk_words * 4, hipMemcpyDeviceToHost));
+        if (ks_out) HIP_TRY(c, hipMemcpy(ks_out, d_ks, ks_words * 4, hipMemcpyDeviceToHost));
+        // load: straight from the device buffers (one device), or through the loaders' fan-out (every device copies from this one)
+        int32_t rc = tfhe_load_bootstrap_key_i32(c, d_bk);
+        if (rc) return rc;
+        return tfhe_load_keyswitch_key(c, d_ks);
+    };
+    const int32_t rc = body();
+    (void)hipSetDevice(g->device);
+    cleanup();
+    return rc;
 }
 
 // ---- launch helpers ------------------------------------------------------------------------------

@@ -81,15 +81,30 @@ class SecretKey:
 class CloudKey:
     """api.jl:111-127.  Holds the flat key arrays; `engine(device)` gives the device context."""
 
-    def __init__(self, rng, secret_key: SecretKey):
+    def __init__(self, rng, secret_key: SecretKey, keygen="host", device=0):
+        """keygen="host": numpy (the reference does this work on the host too); keygen="device": the secret bits and a
+        64-bit seed are drawn from `rng`, the key material is generated on GPU `device` (tfhe_keygen_cloud_key) and
+        the context that made it stays loaded as `engine(device)`."""
         p = secret_key.params
         self.params = p
+        self._engines = {}
         tlwe_key = TLweKey(rng, p.tlwe_polynomial_degree, p.tlwe_mask_size)
+        if keygen == "device":
+            seed = int(rng.integers(0, 2**63))
+            e = _lib.Engine(p, device) if np.ndim(device) == 0 else _lib.Engine(p, devices=[int(d) for d in device])
+            self.bootstrap_key, self.keyswitch_key = e.keygen_cloud_key(secret_key.key.key, tlwe_key.key, p.bs_noise_stddev,
+                                                                        p.ks_noise_stddev, seed)
+            self.bootstrap_key = self.bootstrap_key.reshape(p.lwe_size, p.bs_decomp_length, p.tlwe_mask_size + 1,
+                                                            p.tlwe_mask_size + 1, p.tlwe_polynomial_degree)
+            self._engines[device if np.ndim(device) == 0 else tuple(int(d) for d in device)] = e
+            self.keygen_seed = seed
+            return
+        if keygen != "host":
+            raise ValueError("keygen must be 'host' or 'device'")
         self.bootstrap_key = make_bootstrap_key(rng, p.bs_noise_stddev, secret_key.key, tlwe_key,
                                                 p.bs_decomp_length, p.bs_log2_base)
         self.keyswitch_key = make_keyswitch_key(rng, p.ks_noise_stddev, p.ks_decomp_length, p.ks_log2_base,
                                                 secret_key.key, tlwe_key)
-        self._engines = {}
 
     def engine(self, device=0) -> "_lib.Engine":
         """`device`: a device id, or a sequence of ids for a multi-device context (every batch call is then split
@@ -109,12 +124,12 @@ class CloudKey:
         self._engines = {}
 
 
-def make_key_pair(rng, params: SchemeParameters = None):
-    """api.jl:139-146"""
+def make_key_pair(rng, params: SchemeParameters = None, keygen="host", device=0):
+    """api.jl:139-146 (keygen="device": the cloud key is generated on the GPU, see CloudKey)"""
     if params is None:
         params = tfhe_parameters_80()
     secret_key = SecretKey(rng, params)
-    cloud_key = CloudKey(rng, secret_key)
+    cloud_key = CloudKey(rng, secret_key, keygen=keygen, device=device)
     return secret_key, cloud_key
 
 
