@@ -391,6 +391,7 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
+                "frac_of_measured_copy_rate": achieved / 6.29e12,      # 6.29 TB/s float4 copy (MI355X_MICROARCH.md), quoted beside the 8 TB/s spec
                 "traffic": prof.get("hbm_bytes_per_launch"),
                 "traffic_source": prof.get("source"),
                 "bytes_per_unit": br_bytes(params),
@@ -455,6 +456,36 @@ def profile_counters(kernel_name, units_per_launch):
     return best
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def julia_reference_probe():
+    """if this box happens to have Julia with TFHE.jl installed, time the reference's own gate_nand beside
+    the port; otherwise say what is missing (the reference is Julia and does not travel with the repository)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("julia")
+    if not exe:
+        return "not available: no julia on PATH"
+    script = ("using TFHE, Random; rng = MersenneTwister(123); sk, ck = make_key_pair(rng, tfhe_parameters_80()); "
+              "x = encrypt(rng, sk, true); y = encrypt(rng, sk, false); gate_nand(ck, x, y); "
+              "t = @elapsed for i in 1:5 gate_nand(ck, x, y) end; println(\"ms_per_gate=\", 1000 * t / 5)")
+    try:
+        r = subprocess.run([exe, "-e", script], capture_output=True, text=True, timeout=300)
+    except (OSError, subprocess.TimeoutExpired) as e:
+        return f"not available: {type(e).__name__}"
+    if r.returncode != 0 or "ms_per_gate=" not in r.stdout:
+        return "not available: julia is present but `using TFHE` failed"
+    return {"ms_per_gate_single_thread": float(r.stdout.split("ms_per_gate=")[1].split()[0]), "what": "TFHE.jl gate_nand, tfhe_parameters_80, this box"}
+
+
 def cpu_baseline(tfhe, params, ck, hx, hy, gpu_out, args):
     """The oracle (C restatement of the reference algorithm, reference-style Float64 FFT) timed on this
     box's host cores on a bounded sample of the same workload; also re-checks parity on that sample."""
@@ -478,6 +509,8 @@ def cpu_baseline(tfhe, params, ck, hx, hy, gpu_out, args):
         "value": S / dt,
         "unit": "gates/s",
         "cores": threads,
+        "cpu_model": cpu_model(),
+        "julia_reference": julia_reference_probe(),
         "kind": "port",
         "sample": f"first {S} of the {hx.shape[0]} NAND gates of the GPU workload, one gate per OpenMP thread; "
                   f"C restatement of the reference algorithm (not Julia)",
