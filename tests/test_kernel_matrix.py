@@ -62,21 +62,21 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     eng.set_option("br_variant", 3)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},8>", f"v3<{l},8>")
     eng.set_option("br_variant", 2)
-    eng.set_option("br_small", 512)
+    eng.set_option("br_small", 1024)
     _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
     eng.set_option("br_variant", 1)
     got = eng.bootstrap(MU, x, with_keyswitch=False)
     assert eng.last_kernel_name() == f"blind_rotate_kernel<{l},2>"
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
     eng.set_option("br_variant", 2)
-    # the switch between the two kernels is by batch size: 513 rotations take v3<l,16> without any option
+    # the switch between the two kernels is by batch size: 1025 rotations take v3<l,16> without any option
     eng.set_option("br_tiny", 8)
-    big = np.repeat(x[2:3], 513, axis=0)
-    big[:, 0] += np.arange(513, dtype=np.int32) << 21        # distinct first exponents
-    idx = [0, 1, 7, 8, 511, 512]
-    want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=6)
+    big = np.repeat(x[2:3], 1025, axis=0)
+    big[:, 0] += np.arange(1025, dtype=np.int32) << 21       # distinct first exponents
+    idx = [0, 1, 7, 8, 511, 512, 1023, 1024]
+    want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8)
     for rows, kernel in ((8, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (9, f"blind_rotate_kernel_w2<{l}>"),
-                         (512, f"blind_rotate_kernel_w2<{l}>"), (513, f"blind_rotate_kernel_v3<{l},16>")):
+                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, f"blind_rotate_kernel_v3<{l},16>")):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
         sel = [j for j, r in enumerate(idx) if r < rows]

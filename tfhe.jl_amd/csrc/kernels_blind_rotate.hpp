@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
 //  1.89 ms per gate: a lone wave issues FP64 at about half the SIMD's rate, and four waves transposing at once run into
 //  the CU's LDS store bandwidth, so every transform gets slower as the step gets shorter.)
 template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
+__global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
 {
     constexpr int K1 = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
@@ -940,13 +940,11 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2 waves][kXchElems]
-    cplx *xfer = xch_all + 2 * kXchElems;                                        // [2 parity][2 waves][512]
-    cplx *tw2_lds = xfer + 2 * 2 * kM;                                           // [8][8]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2][kXchElems]: the waves swap them every step
+    cplx *tw2_lds = xch_all + 2 * kXchElems;                                     // [8][8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = tid >> 6;                                                     // wave = owned polynomial
     int32_t *acc_lds = acc_all + wv * kN;
-    cplx *xch = xch_all + wv * kXchElems;
     const size_t w = blockIdx.x;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
@@ -975,6 +973,11 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
         a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         // key polys of transform (p, c = wv): [i][p][c][co][8][64]
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
+        // Transposition buffers: in step i this wave transforms in buffer (wv ^ i) & 1 and leaves its hand-off there; after
+        // the barrier it reads the other wave's hand-off from the other buffer and runs its inverse transform in it — and
+        // keeps that buffer for the forward transforms of step i + 1, while the other wave has moved to this one.  One
+        // barrier per step, no separate hand-off area (27.4 KB of LDS per rotation).
+        cplx *xch = xch_all + ((wv ^ i) & 1) * kXchElems, *xch_next = xch_all + ((wv ^ i ^ 1) & 1) * kXchElems;
         cplx own[8], oth[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); oth[q] = mk(0.0, 0.0); }
@@ -1005,17 +1008,18 @@ __global__ __launch_bounds__(128, 1) void blind_rotate_kernel_w2(BrArgs P)
             for (int k2 = 0; k2 < 8; k2++) oth[k2] = cfma(x[k2], koth[k2], oth[k2]);
             STAMP(2);
         }
-        // hand the other component's partial sum over (buffer by step parity: one barrier per step)
-        cplx *mine = xfer + ((i & 1) * 2 + wv) * kM, *theirs = xfer + ((i & 1) * 2 + (1 - wv)) * kM;
+        // hand the other component's partial sum over
+        WAVE_LDS_FENCE();
 #pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) mine[k2 * 64 + lane] = oth[k2];
+        for (int k2 = 0; k2 < 8; k2++) xch[k2 * 64 + lane] = oth[k2];
         STAMP(3);
         __syncthreads();
         STAMP(4);
 #pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], theirs[k2 * 64 + lane]);
+        for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], xch_next[k2 * 64 + lane]);
+        WAVE_LDS_FENCE();
         STAMP(5);
-        fft_inv_wave(lane, own, tw1f, tw2_lds, xch);
+        fft_inv_wave(lane, own, tw1f, tw2_lds, xch_next);
         STAMP(6);
         int32_t accr[16];
 #pragma unroll
