@@ -20,7 +20,7 @@ truth = {"NAND": lambda x, y, z: ~(x & y), "OR": lambda x, y, z: x | y, "AND": l
          "COPY": lambda x, y, z: x}
 t0 = time.time()
 for it in range(iters):
-    B = int(rng.choice([1, 2, 7, 64, 100, 511, 512, 513, 1000, 2049, 3000]))
+    B = int(rng.choice([1, 2, 7, 9, 64, 100, 511, 513, 900, 1000, 1023, 1025, 1400, 2049, 3000]))
     sel = rng.integers(0, len(names), B)
     ops = np.array([tfhe.OPCODES[names[s]] for s in sel], np.uint8)
     bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
