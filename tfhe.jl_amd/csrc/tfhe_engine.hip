@@ -1535,6 +1535,27 @@ static int32_t read_diag(tfhe_ctx *c, double *worst, double *mhz)
         for (size_t r = 0; r < R; r++)
             if (h[R + 2 * r + 1] > 0) f.push_back((double)h[R + 2 * r] / (double)h[R + 2 * r + 1] * 100.0);
         if (f.empty()) return c->set_err(TFHE_ERR_STATE, "diagnostics: no clock record");
+        if (getenv("TFHE_DEBUG_LIFETIMES")) {       // development aid: wave lifetimes from the 100 MHz s_memrealtime counter
+            double sum = 0, mn = 1e30, mx = 0;
+            for (size_t r = 0; r < R; r++) {
+                const double us = (double)h[R + 2 * r + 1] * 0.01;
+                sum += us; mn = us < mn ? us : mn; mx = us > mx ? us : mx;
+            }
+            fprintf(stderr, "lifetimes of %zu rotations: mean %.1f us, min %.1f, max %.1f\n", R, sum / (double)R, mn, mx);
+            double byx[8] = {0}; size_t nx[8] = {0};
+            for (size_t r = 0; r < R; r++) { byx[r & 7] += (double)h[R + 2 * r + 1] * 0.01; nx[r & 7]++; }
+            fprintf(stderr, "  mean by (rotation mod 8):");
+            for (int x = 0; x < 8; x++) fprintf(stderr, " %.0f", nx[x] ? byx[x] / (double)nx[x] : 0.0);
+            fprintf(stderr, "\n  mean by block of R/8 consecutive rotations:");
+            for (int b = 0; b < 8; b++) {
+                double sb = 0; size_t nb = 0;
+                for (size_t r = b * (R / 8); r < (b + 1) * (R / 8); r++) { sb += (double)h[R + 2 * r + 1] * 0.01; nb++; }
+                fprintf(stderr, " %.0f", nb ? sb / (double)nb : 0.0);
+            }
+            fprintf(stderr, "\n  first 32 lifetimes:");
+            for (size_t r = 0; r < 32 && r < R; r++) fprintf(stderr, " %.0f", (double)h[R + 2 * r + 1] * 0.01);
+            fprintf(stderr, "\n");
+        }
         std::nth_element(f.begin(), f.begin() + (long)(f.size() / 2), f.end());
         *mhz = f[f.size() / 2];
     }
