@@ -131,12 +131,14 @@ def test_edge_cases_and_errors(tfhe, keys80, eng80):
         tfhe.Engine(K.params, 99)                            # no such device
 
 
-def test_full_batch_4096_properties(tfhe, orc, keys80, eng80):
-    """BASELINE config 2 size: every output decrypts to NAND; a sample of indices is bit-equal to the oracle;
-    the batch is deterministic and independent of batch position."""
+@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,16>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
+def test_full_batch_properties(tfhe, orc, keys80, eng80, B, kernel):
+    """BASELINE config 2 size (4096: two rounds of the one-wave kernel) and the chip-filling sizes of the two-wave kernel
+    (1024: four workgroups on every CU, the waves of a workgroup swapping LDS buffers every step; 700: partly filled):
+    every output decrypts to NAND; a sample of indices is bit-equal to the oracle; the batch is deterministic and
+    independent of batch position."""
     K = keys80
     rng = np.random.default_rng(456)
-    B = 4096
     bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
     ops = np.zeros(B, np.uint8)
@@ -147,8 +149,10 @@ def test_full_batch_4096_properties(tfhe, orc, keys80, eng80):
     perm = rng.permutation(B)
     got2 = eng80.gates(ops, x[perm], y[perm])
     assert np.array_equal(got2, got[perm])
-    assert eng80.last_rotation_count() == B
+    assert eng80.last_rotation_count() == B and eng80.last_kernel_name() == kernel
     assert eng80.last_timing_ms(0) > 0 and eng80.last_timing_ms(1) > 0
+    for _ in range(3):                                   # same launch again: no run-to-run difference (a race would show here)
+        assert np.array_equal(eng80.gates(ops, x, y), got)
 
 
 def test_tutorial_encrypted_minimum(tfhe, keys80, eng80):

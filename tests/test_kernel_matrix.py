@@ -204,6 +204,8 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+    for _ in range(2):                               # the same full launch again: every word identical (a race between the two
+        assert np.array_equal(eng.gates(ops, x, y), got)   # waves of a rotation would show as a run-to-run difference)
     eng.set_option("measure_margin", 1)
     again = eng.gates(ops[:256], x[:256], y[:256])
     margin = eng.last_rounding_margin()
@@ -233,6 +235,8 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.985
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
+    for _ in range(2):                               # the same full launch again: every word identical (no race between the waves)
+        assert np.array_equal(eng.mk_gate_nand(x, y), got)
     eng.set_option("measure_margin", 1)
     again = eng.mk_gate_nand(x[:128], y[:128])
     margin = eng.last_rounding_margin()
