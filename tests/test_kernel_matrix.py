@@ -48,8 +48,9 @@ def _check(eng, K, x, expect_kernel, what):
 
 @pytest.mark.parametrize("l", [1, 2, 3, 4])
 def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
-    """blind_rotate_kernel_v3<l,16> (large batches), v3<l,8>, w2<l> (<= 512 rotations), h2<l> (<= 8 rotations, l <= 3),
-    baseline <l,2>: k = 1, N = 1024."""
+    """blind_rotate_kernel_v3<l,16> / v3<l,8> (large batches: whole / half key chunk requested a transform ahead; the default
+    is <2,8> at l = 2 and <l,16> otherwise), w2<l> (<= 1024 rotations), h2<l> (<= 8 rotations, l <= 3), baseline <l,2>:
+    k = 1, N = 1024."""
     K = _setup(tfhe, orc, 1024, 1, l, BETA_1024[l])
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(l), 6, K.params.lwe_size + 1)
@@ -58,25 +59,28 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     eng.set_option("br_tiny", -1)
     _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
     eng.set_option("br_small", -1)
+    default_v3 = f"blind_rotate_kernel_v3<{l},8>" if l == 2 else f"blind_rotate_kernel_v3<{l},16>"
+    _check(eng, K, x, default_v3, "v3 default")
+    eng.set_option("br_variant", 2)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},16>", f"v3<{l},16>")
     eng.set_option("br_variant", 3)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},8>", f"v3<{l},8>")
-    eng.set_option("br_variant", 2)
+    eng.set_option("br_variant", 0)
     eng.set_option("br_small", 1024)
     _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
     eng.set_option("br_variant", 1)
     got = eng.bootstrap(MU, x, with_keyswitch=False)
     assert eng.last_kernel_name() == f"blind_rotate_kernel<{l},2>"
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
-    eng.set_option("br_variant", 2)
-    # the switch between the two kernels is by batch size: 1025 rotations take v3<l,16> without any option
+    eng.set_option("br_variant", 0)
+    # the switch between the two kernels is by batch size: 1025 rotations take the one-wave kernel without any option
     eng.set_option("br_tiny", 8)
     big = np.repeat(x[2:3], 1025, axis=0)
     big[:, 0] += np.arange(1025, dtype=np.int32) << 21       # distinct first exponents
     idx = [0, 1, 7, 8, 511, 512, 1023, 1024]
     want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8)
     for rows, kernel in ((8, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (9, f"blind_rotate_kernel_w2<{l}>"),
-                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, f"blind_rotate_kernel_v3<{l},16>")):
+                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, default_v3)):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
         sel = [j for j, r in enumerate(idx) if r < rows]

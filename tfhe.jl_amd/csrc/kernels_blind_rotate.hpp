@@ -204,6 +204,11 @@ template <int L, int KPF /* key values prefetched per transform: 16 = whole chun
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 {
     constexpr int K1 = 2;
+    // KPF == 8: the first half of a transform's key chunk is requested a transform ahead, the first KMID values of the
+    // second half inside the transform (between the store and the load of its second transposition, where x[] is dead),
+    // the rest after it.  Interleaved A/B on one device, 4096 rotations: l = 2: 12.86 ms against 13.07 with the whole chunk
+    // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  The dispatcher picks by l.
+    constexpr int KMID = (KPF == 8) ? 4 : 0;
     constexpr int F = K1 * L;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
@@ -294,6 +299,13 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
             WAVE_LDS_FENCE();
             x2_store(lane, x, xch);
             WAVE_LDS_FENCE();
+            cplx k1v[8];
+            if (KPF == 8 && KMID > 0) {
+                const cplx *kp = key_ptr(i, f);
+#pragma unroll
+                for (int k2 = 0; k2 < KMID; k2++) k1v[k2] = kp[(8 + k2) * 64];
+                WAVE_LDS_FENCE();
+            }
             x2_load(lane, x, xch);
             WAVE_LDS_FENCE();
             dft8<false>(x);
@@ -305,9 +317,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
                     for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
             } else {
                 const cplx *kp = key_ptr(i, f);
-                cplx k1v[8];
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
+                for (int k2 = KMID; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kbuf[k2], out[0][k2]);
 #pragma unroll

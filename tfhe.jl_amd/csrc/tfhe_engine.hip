@@ -78,7 +78,8 @@ struct tfhe_ctx {
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
     int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
-    int br_variant = 2;          // 1 = baseline kernel, 2 = v3 full-chunk key prefetch (default), 3 = v3 half-chunk
+    int br_variant = 0;          // 0 = by decomposition length (default: 3 for l = 2, else 2), 1 = baseline kernel, 2 = v3 with the whole key chunk
+                                 // requested a transform ahead, 3 = v3 with half of it ahead and the rest inside / after the transform
 
     // tables
     cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
@@ -628,7 +629,8 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         name_kernel(c, "blind_rotate_kernel_k2<%d>", L);
         return TFHE_OK;
     }
-    if ((c->br_tiny >= 0 && (int64_t)R <= c->br_tiny) && c->br_variant >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
+    const int brv = c->br_variant ? c->br_variant : (L == 2 ? 3 : 2);      // 0 = by decomposition length
+    if ((c->br_tiny >= 0 && (int64_t)R <= c->br_tiny) && brv >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
@@ -646,7 +648,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         name_kernel(c, "blind_rotate_kernel_h2<%d>", L);
         return TFHE_OK;
     }
-    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && c->br_variant >= 2) {
+    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && brv >= 2) {
         // 27.4 KB of LDS and < 256 registers per wave: four workgroups per CU, 1024 rotations resident at two waves per SIMD
         const size_t ldsw = 2 * kN * 4 + (2 * kXchElems + 64) * sizeof(cplx);
 #define LAUNCH_W2(LL)                                                                                              \
@@ -658,9 +660,9 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         name_kernel(c, "blind_rotate_kernel_w2<%d>", L);
         return TFHE_OK;
     }
-    if (c->br_variant >= 2) {
+    if (brv >= 2) {
         const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-        const bool half = (c->br_variant == 3);
+        const bool half = (brv == 3);
 #define LAUNCH_V3(LL)                                                                                              \
         if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
         else if (half) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
@@ -1620,7 +1622,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "br_variant")) {
-        if (value < 1 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 1, 2 or 3");
+        if (value < 0 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 0 (by decomposition length), 1, 2 or 3");
         c->br_variant = (int)value;
         return TFHE_OK;
     }
