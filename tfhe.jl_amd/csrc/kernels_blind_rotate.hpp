@@ -80,7 +80,24 @@ struct BrArgs {
     Gadget g;
     int32_t n;
     int32_t mu;
+    int32_t prio_steps;   // a wave runs its first prio_steps CMUX steps at raised issue priority (wave_priority_* below); 0: never
 };
+
+// Issue priority by progress.  The SIMD's arbiter favours the OLDER of its two waves: the first-placed wave of a SIMD runs
+// at nearly the speed of a lone wave (4.7 ms per rotation in blind_rotate_kernel_v3) and the second-placed one takes 7.0 ms,
+// finishing alone; at the end of a launch every SIMD is left with one wave for milliseconds.  A wave that raises its own
+// priority (s_setprio 1) for the first ~60 % of its steps overtakes an older partner that is already past that point, so
+// the two waves of a SIMD stay closer together and the launch ends with less lone-wave time: 12.7 vs 13.3 ms for 4096
+// rotations, 6.6 vs 6.9 ms for 2048 (same device); N = 2048: 48.0 vs 49.0 ms, 2-party multi-key: 17.7 vs 18.2 ms
+// (option br_prio_pct; 30 and 80 % give about half the gain).
+__device__ __forceinline__ void wave_priority_begin(int prio_steps)
+{
+    if (prio_steps > 0) __builtin_amdgcn_s_setprio(1);
+}
+__device__ __forceinline__ void wave_priority_step(int step, int prio_steps)
+{
+    if (step == prio_steps) __builtin_amdgcn_s_setprio(0);
+}
 
 template <int K1>
 __device__ __forceinline__ void store_acc(int lane, const int32_t (&acc)[16], int32_t *acc_lds)
@@ -210,6 +227,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  The dispatcher picks by l.
     constexpr int KMID = (KPF == 8) ? 4 : 0;
     constexpr int F = K1 * L;
+    wave_priority_begin(P.prio_steps);
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,6 +277,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     for (int i = 0; i < P.n; i++) {
         const int a = a_next;
         a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        wave_priority_step(i, P.prio_steps);
 
         cplx out[K1][8];
 #pragma unroll
@@ -394,6 +413,7 @@ struct MkBrArgs {
     Gadget g;
     int32_t n;
     int32_t mu;
+    int32_t prio_steps;   // of the P * n steps of a rotation; see wave_priority_begin
 };
 
 // `mid()` runs between the store and the load of the second transposition, when x[] is dead: the place to request global
@@ -608,6 +628,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
     STAMP_DECL;
 #pragma unroll 1
     for (int j = 0; j < P.n; j++) {
+        wave_priority_step(PARTY * P.n + j, P.prio_steps);
         const int a = a_next;
         a_next = bara[PARTY * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
         const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
@@ -754,6 +775,7 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
         }
     }
     __syncthreads();
+    wave_priority_begin(P.prio_steps);
     // party-major double loop (mk_internals.jl:475-476)
     if (wv == 0) {
         mk2_party_steps<L, 0, 0, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
@@ -980,8 +1002,10 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     STAMP_DECL;
 
     int a_next = bara[0] & (2 * kN - 1);
+    wave_priority_begin(P.prio_steps);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
+        wave_priority_step(i, P.prio_steps);
         const int a = a_next;
         a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         // key polys of transform (p, c = wv): [i][p][c][co][8][64]
@@ -1353,6 +1377,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     }
     WAVE_LDS_FENCE();
 
+    // (no wave_priority_* here: measured 1 % slower with it on this kernel)
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         const int a = bara[i] & (2 * kN - 1);
@@ -1451,6 +1476,7 @@ struct Br2048Args {
     Gadget g;
     int32_t n, mu;
     int32_t R;             // rotations in the batch (workgroups hold several: the last one may be padded)
+    int32_t prio_steps;    // see wave_priority_begin
 };
 
 // pass-A input from the four coefficient classes of point jj = t + 64 r (values already converted to double)
@@ -1533,8 +1559,10 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     STAMP_DECL;
 
     int a_next = bara[0] & (2 * kN2 - 1);
+    wave_priority_begin(P.prio_steps);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
+        wave_priority_step(i, P.prio_steps);
         const int a = a_next;
         a_next = bara[i + 1] & (2 * kN2 - 1);   // bara[n] (= barb) exists: harmless read on the last step
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;

@@ -76,6 +76,7 @@ struct tfhe_ctx {
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
+    int br_prio_pct = 60;        // a wave of the batched kernels runs this share of its steps at raised issue priority (0: off)
     int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
     int br_variant = 0;          // 0 = by decomposition length (default: 3 for l = 2, else 2), 1 = baseline kernel, 2 = v3 with the whole key chunk
@@ -586,10 +587,11 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.g = c->g;
     a.n = c->P.n;
     a.mu = mu;
+    a.prio_steps = (int32_t)((int64_t)c->P.n * c->br_prio_pct / 100);
     const int L = c->P.bs_l;
     if (c->P.N == kN2) {
         Br2048Args b;
-        b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu;
+        b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
         // n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation per workgroup)
         const int rw = c->n2048_rw;
@@ -1354,6 +1356,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     const bool dg = c->measure_margin;
     a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
     a.n = n; a.mu = (int32_t)(1u << 29); a.R = (int32_t)B;
+    a.prio_steps = (int32_t)((int64_t)NP * n * c->br_prio_pct / 100);
     const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
     if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
@@ -1628,6 +1631,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
+    if (!strcmp(name, "br_prio_pct")) {
+        if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
+        c->br_prio_pct = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "ks_slices")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: ks_slices must be 1, 2 or 4");
         c->ks_slices_large = (int)value;
