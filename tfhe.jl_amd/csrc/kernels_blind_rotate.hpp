@@ -80,23 +80,27 @@ struct BrArgs {
     Gadget g;
     int32_t n;
     int32_t mu;
-    int32_t prio_steps;   // a wave runs its first prio_steps CMUX steps at raised issue priority (wave_priority_* below); 0: never
+    int32_t prio_steps;   // a wave lowers its issue priority 3 -> 2 -> 1 -> 0 over its first prio_steps CMUX steps (wave_priority_* below); 0: never
 };
 
 // Issue priority by progress.  The SIMD's arbiter favours the OLDER of its two waves: the first-placed wave of a SIMD runs
 // at nearly the speed of a lone wave (4.7 ms per rotation in blind_rotate_kernel_v3) and the second-placed one takes 7.0 ms,
-// finishing alone; at the end of a launch every SIMD is left with one wave for milliseconds.  A wave that raises its own
-// priority (s_setprio 1) for the first ~60 % of its steps overtakes an older partner that is already past that point, so
-// the two waves of a SIMD stay closer together and the launch ends with less lone-wave time: 12.7 vs 13.3 ms for 4096
-// rotations, 6.6 vs 6.9 ms for 2048 (same device); N = 2048: 48.0 vs 49.0 ms, 2-party multi-key: 17.7 vs 18.2 ms
-// (option br_prio_pct; 30 and 80 % give about half the gain).
+// finishing alone; at the end of a launch every SIMD is left with one wave for milliseconds.  Here a wave sets its own
+// priority by its progress (s_setprio 3, 2, 1, 0 over the thirds of its first prio_steps steps, 90 % of the rotation by
+// default): the wave with more work left is favoured, the two waves of a SIMD stay closer together and the launch ends
+// with less lone-wave time.  Same device, 4096 rotations: 12.64 ms against 13.01 without (12.81 with a single level for the
+// first 60 %); 2048 rotations: 6.29 against 6.65; N = 2048: 48.0 vs 49.0 ms, 2-party multi-key: 17.7 vs 18.2 ms with a
+// single level.  Option br_prio_pct.
 __device__ __forceinline__ void wave_priority_begin(int prio_steps)
 {
-    if (prio_steps > 0) __builtin_amdgcn_s_setprio(1);
+    if (prio_steps > 0) __builtin_amdgcn_s_setprio(3);
 }
 __device__ __forceinline__ void wave_priority_step(int step, int prio_steps)
 {
-    if (step == prio_steps) __builtin_amdgcn_s_setprio(0);
+    if (prio_steps <= 0) return;
+    if (step == prio_steps / 3) __builtin_amdgcn_s_setprio(2);
+    else if (step == 2 * prio_steps / 3) __builtin_amdgcn_s_setprio(1);
+    else if (step == prio_steps) __builtin_amdgcn_s_setprio(0);
 }
 
 template <int K1>

@@ -76,7 +76,7 @@ struct tfhe_ctx {
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
-    int br_prio_pct = 60;        // a wave of the batched kernels runs this share of its steps at raised issue priority (0: off)
+    int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
     int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
     int br_variant = 0;          // 0 = by decomposition length (default: 3 for l = 2, else 2), 1 = baseline kernel, 2 = v3 with the whole key chunk
