@@ -153,6 +153,10 @@ def test_full_batch_properties(tfhe, orc, keys80, eng80, B, kernel):
     assert eng80.last_timing_ms(0) > 0 and eng80.last_timing_ms(1) > 0
     for _ in range(3):                                   # same launch again: no run-to-run difference (a race would show here)
         assert np.array_equal(eng80.gates(ops, x, y), got)
+    for pct in (0, 50, 100):                             # the issue-priority schedule changes timing only
+        eng80.set_option("br_prio_pct", pct)
+        assert np.array_equal(eng80.gates(ops, x, y), got), pct
+    eng80.set_option("br_prio_pct", 90)
 
 
 def test_tutorial_encrypted_minimum(tfhe, keys80, eng80):

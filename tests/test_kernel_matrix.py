@@ -210,6 +210,9 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
     for _ in range(2):                               # the same full launch again: every word identical (a race between the two
         assert np.array_equal(eng.gates(ops, x, y), got)   # waves of a rotation would show as a run-to-run difference)
+    eng.set_option("br_prio_pct", 0)                 # without the issue-priority schedule: same words
+    assert np.array_equal(eng.gates(ops, x, y), got)
+    eng.set_option("br_prio_pct", 90)
     eng.set_option("measure_margin", 1)
     again = eng.gates(ops[:256], x[:256], y[:256])
     margin = eng.last_rounding_margin()
@@ -241,6 +244,9 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
     for _ in range(2):                               # the same full launch again: every word identical (no race between the waves)
         assert np.array_equal(eng.mk_gate_nand(x, y), got)
+    eng.set_option("br_prio_pct", 0)                 # without the issue-priority schedule: same words
+    assert np.array_equal(eng.mk_gate_nand(x, y), got)
+    eng.set_option("br_prio_pct", 90)
     eng.set_option("measure_margin", 1)
     again = eng.mk_gate_nand(x[:128], y[:128])
     margin = eng.last_rounding_margin()
