@@ -458,13 +458,17 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     HIP_TRY(c, hipMalloc((void **)&d_canon, bytes));
     const int mode = pick_ks_mode(c);
     auto body = [&]() -> int32_t {
-        HIP_TRY(c, hipMemcpy(d_canon, ks, bytes, hipMemcpyDefault));          // host pointer, or a device buffer (tfhe_keygen_cloud_key)
+        // host pointer, or a device buffer (tfhe_keygen_cloud_key).  On the context's stream, like everything that consumes
+        // d_canon below: a device-to-device hipMemcpy is NOT synchronous with the host and runs on the NULL stream, which
+        // this context's non-blocking stream does not wait for
+        HIP_TRY(c, hipMemcpyAsync(d_canon, ks, bytes, hipMemcpyDefault, c->stream));
         if (mode == 3) {   // row-padded copy: stride = n+1 rounded up to 4 words so that rows are 16-byte aligned
             const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
             const size_t rows = ks_word_count(c->P) / n1;
             HIP_TRY(c, hipMalloc((void **)&c->d_ksp, rows * stride * 4));
-            HIP_TRY(c, hipMemset(c->d_ksp, 0, rows * stride * 4));
-            HIP_TRY(c, hipMemcpy2D(c->d_ksp, stride * 4, d_canon, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice));
+            HIP_TRY(c, hipMemsetAsync(c->d_ksp, 0, rows * stride * 4, c->stream));
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_ksp, stride * 4, d_canon, n1 * 4, n1 * 4, rows, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
             c->ks_stride = (int)stride;
         } else if (mode == 4) {
             const int kNn = c->P.k * c->P.N, wtiles = (c->P.n + 1 + 31) / 32;
@@ -476,6 +480,7 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             c->ks4_wtiles = wtiles;
         }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // the caller's buffer is free again, the key is complete for any stream
         return TFHE_OK;
     };
     const int32_t rc = body();
