@@ -109,7 +109,7 @@ struct tfhe_ctx {
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
-    int mkg_rw = 0;                // any-party kernel: cap on the rotations per workgroup (0: as many as fit, at most 4)
+    int mkg_rw = 0;                // any-party kernel: rotations per workgroup, in lockstep (0: two; otherwise a cap, at most 4 and what fits in LDS)
     int mkg_acc = -1;              // any-party kernel: accumulators in LDS (0) / in global memory (1) / by party count (-1: global above 4 parties)
     int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
@@ -1403,7 +1403,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         const bool accg = c->mkg_acc < 0 ? NP > 4 : c->mkg_acc != 0;
         const size_t lds_rot = accg ? (kXchElems + 64) * sizeof(cplx) : lds;
         int rw = (int)std::min<size_t>(4, (160 * 1024) / lds_rot);
-        if (c->mkg_rw > 0) rw = std::min(rw, c->mkg_rw);
+        rw = std::min(rw, c->mkg_rw > 0 ? c->mkg_rw : 2);      // default two: 82 vs 86 ms (four or one) at 4 parties, 476 vs 481 / 765 at 8
         if (B < 2) rw = 1;
         const size_t ldsg = (size_t)rw * lds_rot;
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
