@@ -1,30 +1,43 @@
-# TFHEMI355X.jl — ccall shim that puts libtfhe_mi355x.so behind TFHE.jl's own gate API.
+# TFHEMI355X.jl — puts libtfhe_mi355x.so behind TFHE.jl's OWN gate functions.
 #
-# NOT EXECUTED IN THE BUILD IMAGE (no Julia there): kept literal and small so it can be reviewed by
-# reading against include/tfhe_mi355x.h.  Usage (on a box with Julia, TFHE.jl and one or more MI355X):
+# NOT EXECUTED IN THE BUILD IMAGE (no Julia there): kept literal so it can be reviewed by reading against
+# include/tfhe_mi355x.h; tests/test_julia_shim.py checks every ccall against the header, that no TFHE name is exported
+# without being imported from TFHE, and that every exported gate has its batched `broadcasted` method.
+#
+# The module defines NO function named gate_*: it `import`s TFHE's functions (src/TFHE.jl:34-46,61) and adds methods
+# whose cloud-key argument is a GpuCloudKey / GpuMKCloudKey.  After
 #
 #     using TFHE, Random
-#     include("julia/TFHEMI355X.jl"); using .TFHEMI355X
+#     include("julia/TFHEMI355X.jl"); using .TFHEMI355X       # exports only GpuCloudKey, GpuMKCloudKey, GpuLweArray, ...
 #     rng = MersenneTwister(123)
 #     secret_key, cloud_key = make_key_pair(rng)
-#     gck = GpuCloudKey(cloud_key)                      # flattens + uploads the keys once (device 0)
-#     gck8 = GpuCloudKey(cloud_key; devices=0:7)        # keys replicated on 8 GPUs, every batch call split over them
-#     r = gate_nand(gck, encrypt(rng, secret_key, true), encrypt(rng, secret_key, false))
-#     rs = gate_nand(gck8, xs, ys)                      # Vector{LweSample}: ONE batched call (the analogue of
-#                                                       # gate_nand.(cloud_key, xs, ys), docs/src/manual.md:28-35)
-#     mck = GpuMKCloudKey(mk_cloud_key)                 # multi-key: MKCloudKey -> device
-#     out = mk_gate_nand(mck, x, y)                     # MKLweSample (or vectors of them)
+#     gck = GpuCloudKey(cloud_key)                            # flattens + uploads the keys once (device 0)
 #
-# Every method has the name and argument order of the TFHE.jl function it replaces
-# (src/gates.jl:15-177, src/mk_gates.jl:7-12); the cloud-key argument is a GpuCloudKey / GpuMKCloudKey.
+# the reference's caller lines run unchanged with `gck` where they say `cloud_key`:
+#
+#     cresult = gate_xor.(gck, ciphertext1, ciphertext2)      # docs/src/manual.md:35 — ONE tfhe_gates_batch call
+#     tmp = gate_xnor(gck, a, b); gate_mux(gck, tmp, lsb_carry, a)          # examples/tutorial.jl:44-45
+#     tmps1 = gate_constant(gck, false)                       # examples/tutorial.jl:54
+#     [gate_mux(gck, tmps1, b[i], a[i]) for i in 1:nb_bits]   # examples/tutorial.jl:62 (or gate_mux.(gck, tmps1, b, a): one call)
+#     enc_out = mk_gate_nand(mck, enc_mess1, enc_mess2)       # test/runtests.jl:95, mck = GpuMKCloudKey(cloud_key)
+#
+# (examples/tutorial.jl annotates its own helper functions `ck::CloudKey`; to pass a GpuCloudKey through them the
+# annotation has to be dropped or widened — CloudKey is a concrete struct, nothing can subtype it.)
+#
+#     gck8 = GpuCloudKey(cloud_key; devices=0:7)              # keys replicated on 8 GPUs, every batch call split over them
+#     d1 = upload(gck, ciphertext1); d2 = upload(gck, ciphertext2)          # GpuLweArray: ciphertexts resident on the GPU
+#     d3 = gate_and.(gck, gate_xor.(gck, d1, d2), d1)         # stays on the device between gates (tfhe_gates_level)
+#     result = download(d3)                                   # Vector{LweSample}
 module TFHEMI355X
 
 using TFHE
+import TFHE: gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not, gate_constant,
+             gate_nor, gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux, mk_gate_nand
 using TFHE: LweSample, LweParams, CloudKey, SecretKey, SchemeParameters, MKCloudKey, MKLweSample
 using Random: AbstractRNG
+import Base.Broadcast: broadcastable, broadcasted
 
-export GpuCloudKey, GpuMKCloudKey, gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not, gate_constant,
-       gate_nor, gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux, gates_batch, mk_gate_nand
+export GpuCloudKey, GpuMKCloudKey, GpuLweArray, gates_batch, upload, download
 
 const LIB = get(ENV, "TFHE_MI355X_LIB", joinpath(@__DIR__, "..", "tfhe.jl_amd", "lib", "libtfhe_mi355x.so"))
 
@@ -86,41 +99,81 @@ function flatten_bootstrap_spectra(bk, p::SchemeParameters)
     spectra
 end
 
+"""
+    GpuCloudKey(ck::CloudKey; device=0, devices=nothing, wires=65536)
+    GpuCloudKey(rng, secret_key::SecretKey; device=0, devices=nothing, wires=65536)
+
+A `CloudKey` resident on one MI355X (`device`) or replicated on several (`devices=0:7`).  Pass it to TFHE's own
+`gate_*` functions in place of the `CloudKey`.  `wires` is the capacity (in ciphertexts) of the device-resident table
+behind [`GpuLweArray`](@ref); it is allocated on first use.
+"""
 mutable struct GpuCloudKey
     params::SchemeParameters
     ctx::Ptr{Cvoid}
+    # device-resident ciphertexts (tfhe_wires_*): rows of one table, handed out here, handed back by GpuLweArray finalizers
+    wire_capacity::Int
+    wire_ready::Bool                       # tfhe_wires_alloc done
+    wire_next::Int
+    wire_free::Vector{Int32}
+    wire_returned::Vector{Vector{Int32}}
 
-    function GpuCloudKey(ck::CloudKey; device::Integer=0, devices=nothing)
-        p = ck.params
-        ctx = create_context(p, devices === nothing ? [device] : devices)
-        spectra = flatten_bootstrap_spectra(ck.bootstrap_key, p)
-        GC.@preserve spectra check(ctx, ccall((:tfhe_load_bootstrap_key_c128, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Complex{Float64}}), ctx, spectra))
-        flat = flatten_keyswitch_key(ck.keyswitch_key, p.lwe_size)
-        GC.@preserve flat check(ctx, ccall((:tfhe_load_keyswitch_key, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Int32}), ctx, flat))
-        gck = new(p, ctx)
-        finalizer(g -> ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx), gck)
-        gck
-    end
-
-    # The cloud key generated ON THE GPU (tfhe_keygen_cloud_key) instead of by CloudKey(rng, secret_key) on the host
-    # (api.jl:111-127): the TLWE key bits and a 64-bit seed come from `rng`, the bootstrap and keyswitch keys never
-    # exist on the host.  The key material follows the library's Philox streams, not MersenneTwister's.
-    function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing)
-        p = secret_key.params
-        ctx = create_context(p, devices === nothing ? [device] : devices)
-        lwe_bits = Int32.(secret_key.key.key)                                        # lwe.jl:11-17
-        tlwe_bits = Int32.(rand(rng, Bool, p.tlwe_polynomial_degree, p.tlwe_mask_size))   # [N, k] = C-order [k][N]; tlwe.jl:15-20
-        seed = rand(rng, UInt64)
-        GC.@preserve lwe_bits tlwe_bits check(ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, UInt64, Ptr{Int32}, Ptr{Int32}),
-            ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
-        gck = new(p, ctx)
-        finalizer(g -> ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx), gck)
+    # the finalizer is attached before anything that can throw: a failed key load does not leak the context
+    function GpuCloudKey(p::SchemeParameters, devices, wires::Integer)
+        ctx = create_context(p, devices)
+        gck = new(p, ctx, Int(wires), false, 0, Int32[], Vector{Vector{Int32}}())
+        finalizer(destroy!, gck)
         gck
     end
 end
+
+function destroy!(g)
+    if g.ctx != C_NULL
+        ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx)
+        g.ctx = C_NULL
+    end
+    nothing
+end
+
+function GpuCloudKey(ck::CloudKey; device::Integer=0, devices=nothing, wires::Integer=65536)
+    p = ck.params
+    gck = GpuCloudKey(p, devices === nothing ? [device] : devices, wires)
+    try
+        spectra = flatten_bootstrap_spectra(ck.bootstrap_key, p)
+        GC.@preserve spectra check(gck.ctx, ccall((:tfhe_load_bootstrap_key_c128, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Complex{Float64}}), gck.ctx, spectra))
+        flat = flatten_keyswitch_key(ck.keyswitch_key, p.lwe_size)
+        GC.@preserve flat check(gck.ctx, ccall((:tfhe_load_keyswitch_key, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Int32}), gck.ctx, flat))
+    catch
+        destroy!(gck)
+        rethrow()
+    end
+    gck
+end
+
+# The cloud key generated ON THE GPU (tfhe_keygen_cloud_key) instead of by CloudKey(rng, secret_key) on the host
+# (api.jl:111-127): the TLWE key bits and a 64-bit seed come from `rng`, the bootstrap and keyswitch keys never exist
+# on the host.  The key material follows the library's Philox streams, not MersenneTwister's.  The seed is as secret
+# as the secret key (it regenerates the noise of every key row): it is not stored anywhere.
+function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing, wires::Integer=65536)
+    p = secret_key.params
+    gck = GpuCloudKey(p, devices === nothing ? [device] : devices, wires)
+    try
+        lwe_bits = Int32.(secret_key.key.key)                                        # lwe.jl:11-17
+        tlwe_bits = Int32.(rand(rng, Bool, p.tlwe_polynomial_degree, p.tlwe_mask_size))   # [N, k] = C-order [k][N]; tlwe.jl:15-20
+        seed = rand(rng, UInt64)
+        GC.@preserve lwe_bits tlwe_bits check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, UInt64, Ptr{Int32}, Ptr{Int32}),
+            gck.ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
+    catch
+        destroy!(gck)
+        rethrow()
+    end
+    gck
+end
+
+# a GpuCloudKey is a scalar under broadcasting, as CloudKey is (src/api.jl:130)
+broadcastable(g::GpuCloudKey) = Ref(g)
 
 # LweSample <-> flat Int32[n+1] (a then b), include/tfhe_mi355x.h
 function flatten(xs::AbstractVector{LweSample})
@@ -137,14 +190,119 @@ unflatten(m::Matrix{Int32}, params::LweParams) =
     # current_variance is write-only bookkeeping in the reference (SURVEY §5); 0.0 as tlwe.jl:58 does
     [LweSample(params, m[1:end-1, g], m[end, g], 0.) for g in 1:size(m, 2)]
 
+# ---- device-resident ciphertexts ------------------------------------------------------------------------------------
 """
-    gates_batch(gck, opcodes, xs, ys, zs)
+    GpuLweArray
 
-`length(opcodes)` independent gates in one GPU call (tfhe_gates_batch).
+A vector of LWE samples resident on the GPU (rows of the key's wire table, tfhe_wires_*).  `upload(gck, xs)` makes
+one, `download(d)` brings it back as `Vector{LweSample}`; gates on GpuLweArrays run through `tfhe_gates_level` and
+return GpuLweArrays, so a circuit's intermediate ciphertexts never cross PCIe and are never re-flattened.
+"""
+mutable struct GpuLweArray
+    key::GpuCloudKey
+    rows::Vector{Int32}            # wire indices (0-based)
+
+    function GpuLweArray(key::GpuCloudKey, rows::Vector{Int32})
+        d = new(key, rows)
+        # a finalizer must not call into the allocator: it only queues the rows; alloc_rows! takes them back
+        finalizer(a -> push!(a.key.wire_returned, a.rows), d)
+        d
+    end
+end
+
+Base.length(d::GpuLweArray) = length(d.rows)
+
+function alloc_rows!(g::GpuCloudKey, count::Int)
+    if !g.wire_ready                                                       # first use: allocate the table
+        check(g.ctx, ccall((:tfhe_wires_alloc, LIB), Int32, (Ptr{Cvoid}, Int64), g.ctx, g.wire_capacity))
+        g.wire_ready = true
+    end
+    returned = g.wire_returned
+    g.wire_returned = Vector{Vector{Int32}}()
+    for r in returned
+        append!(g.wire_free, r)
+    end
+    rows = Vector{Int32}(undef, count)
+    reused = min(count, length(g.wire_free))
+    for i in 1:reused
+        rows[i] = pop!(g.wire_free)
+    end
+    fresh = count - reused
+    if g.wire_next + fresh > g.wire_capacity
+        append!(g.wire_free, rows[1:reused])
+        error("GpuLweArray: wire table full ($(g.wire_capacity) ciphertexts); construct the GpuCloudKey with a larger `wires`")
+    end
+    for i in 1:fresh
+        rows[reused + i] = g.wire_next + i - 1
+    end
+    g.wire_next += fresh
+    rows
+end
+
+"""
+    upload(gck, xs::AbstractVector{LweSample}) -> GpuLweArray
+"""
+function upload(g::GpuCloudKey, xs::AbstractVector{LweSample})
+    rows = alloc_rows!(g, length(xs))
+    isempty(xs) && return GpuLweArray(g, rows)
+    flat = flatten(xs)
+    first_fresh = isempty(rows) ? 0 : rows[1]
+    contiguous = all(rows[i] == first_fresh + i - 1 for i in 1:length(rows))
+    if contiguous
+        GC.@preserve flat check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}), g.ctx, first_fresh, length(rows), flat))
+    else                                                                 # recycled rows: one copy per row
+        n1 = size(flat, 1)
+        for (i, r) in enumerate(rows)
+            GC.@preserve flat check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}), g.ctx, r, 1, pointer(flat, (i - 1) * n1 + 1)))
+        end
+    end
+    GpuLweArray(g, rows)
+end
+
+"""
+    download(d::GpuLweArray) -> Vector{LweSample}
+"""
+function download(d::GpuLweArray)
+    g = d.key
+    out = Array{Int32}(undef, g.params.lwe_size + 1, length(d))
+    GC.@preserve out check(g.ctx, ccall((:tfhe_wires_gather, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Int32}, Int64, Ptr{Int32}), g.ctx, d.rows, length(d), out))
+    unflatten(out, LweParams(g.params.lwe_size))
+end
+
+# ---- the batch calls ------------------------------------------------------------------------------------------------
+const LweVec = AbstractVector{LweSample}
+const LweOperand = Union{LweSample, LweVec, GpuLweArray}
+
+operand_length(x::LweSample) = 1
+operand_length(x) = length(x)
+
+# the common length of the vector operands (scalars repeat, as under broadcasting)
+function batch_length(operands)
+    B = 1
+    for x in operands
+        x isa LweSample && continue
+        L = operand_length(x)
+        (B == 1 || L == B || L == 1) || throw(DimensionMismatch("gate operands of lengths $B and $L"))
+        B = max(B, L)
+    end
+    B
+end
+
+expand(x::LweSample, B) = fill(x, B)
+expand(xs::LweVec, B) = length(xs) == B ? xs : fill(xs[1], B)
+
+"""
+    gates_batch(gck, opcodes, xs, ys=nothing, zs=nothing)
+
+`length(opcodes)` independent gates, one opcode per gate, in one GPU call (tfhe_gates_batch).
 """
 function gates_batch(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=nothing, zs=nothing)
     B = length(opcodes)
     params = LweParams(gck.params.lwe_size)
+    B == 0 && return LweSample[]
     fx = xs === nothing ? nothing : flatten(xs)
     fy = ys === nothing ? nothing : flatten(ys)
     fz = zs === nothing ? nothing : flatten(zs)
@@ -156,26 +314,68 @@ function gates_batch(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=nothing, z
     unflatten(out, params)
 end
 
-# scalar and vector methods with the reference's names (src/gates.jl)
-for (name, op) in ((:gate_nand, NAND), (:gate_or, OR), (:gate_and, AND), (:gate_xor, XOR),
-                   (:gate_xnor, XNOR), (:gate_nor, NOR), (:gate_andny, ANDNY), (:gate_andyn, ANDYN),
-                   (:gate_orny, ORNY), (:gate_oryn, ORYN))
+# one level of B gates on device-resident operands (tfhe_gates_level); host samples among them are uploaded first
+function gates_on_device(g::GpuCloudKey, op::UInt8, operands)
+    B = batch_length(operands)
+    devs = map(operands) do x
+        d = x isa GpuLweArray ? x : upload(g, x isa LweSample ? [x] : x)
+        d.key === g || error("GpuLweArray belongs to another GpuCloudKey")
+        d
+    end
+    index(d) = length(d) == B ? d.rows : fill(d.rows[1], B)
+    ia = index(devs[1])
+    ib = length(devs) >= 2 ? index(devs[2]) : Int32[]
+    ic = length(devs) >= 3 ? index(devs[3]) : Int32[]
+    out = alloc_rows!(g, B)
+    opcodes = fill(op, B)
+    ptr(a) = isempty(a) ? Ptr{Int32}(C_NULL) : pointer(a)
+    GC.@preserve opcodes ia ib ic out devs check(g.ctx, ccall((:tfhe_gates_level, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64),
+        g.ctx, opcodes, ptr(ia), ptr(ib), ptr(ic), out, B))
+    GpuLweArray(g, out)
+end
+
+# One gate kind over scalar / vector / device operands: all LweSample -> a LweSample (batch of one); any vector ->
+# Vector{LweSample} from ONE tfhe_gates_batch; any GpuLweArray -> a GpuLweArray (nothing leaves the device).
+function run_gate(g::GpuCloudKey, op::UInt8, operands...)
+    any(x -> x isa GpuLweArray, operands) && return gates_on_device(g, op, operands)
+    B = batch_length(operands)
+    vecs = map(x -> expand(x, B), operands)
+    res = gates_batch(g, fill(op, B), vecs...)
+    all(x -> x isa LweSample, operands) ? res[1] : res
+end
+
+# Methods ON TFHE's functions (src/gates.jl:15-153), and the batched forms of their broadcast: gate_xor.(gck, c1, c2)
+# (docs/src/manual.md:35) lowers to broadcasted(gate_xor, gck, c1, c2), which these methods answer with one GPU call
+# instead of length(c1) single-gate launches.
+for (fn, op) in ((:gate_nand, NAND), (:gate_or, OR), (:gate_and, AND), (:gate_xor, XOR),
+                 (:gate_xnor, XNOR), (:gate_nor, NOR), (:gate_andny, ANDNY), (:gate_andyn, ANDYN),
+                 (:gate_orny, ORNY), (:gate_oryn, ORYN))
     @eval begin
-        $name(gck::GpuCloudKey, x::LweSample, y::LweSample) = gates_batch(gck, [$op], [x], [y])[1]
-        $name(gck::GpuCloudKey, xs::AbstractVector{LweSample}, ys::AbstractVector{LweSample}) =
-            gates_batch(gck, fill($op, length(xs)), xs, ys)
+        $fn(g::GpuCloudKey, x::LweOperand, y::LweOperand) = run_gate(g, $op, x, y)
+        broadcasted(::typeof($fn), g::GpuCloudKey, x::LweOperand, y::LweOperand) = run_gate(g, $op, x, y)
+        broadcasted(::typeof($fn), g::Base.RefValue{GpuCloudKey}, x::LweOperand, y::LweOperand) = run_gate(g[], $op, x, y)
     end
 end
 
-gate_mux(gck::GpuCloudKey, x::LweSample, y::LweSample, z::LweSample) =
-    gates_batch(gck, [MUX], [x], [y], [z])[1]
-gate_mux(gck::GpuCloudKey, xs::AbstractVector{LweSample}, ys::AbstractVector{LweSample},
-         zs::AbstractVector{LweSample}) = gates_batch(gck, fill(MUX, length(xs)), xs, ys, zs)
+# src/gates.jl:163-177
+gate_mux(g::GpuCloudKey, x::LweOperand, y::LweOperand, z::LweOperand) = run_gate(g, MUX, x, y, z)
+broadcasted(::typeof(gate_mux), g::GpuCloudKey, x::LweOperand, y::LweOperand, z::LweOperand) = run_gate(g, MUX, x, y, z)
+broadcasted(::typeof(gate_mux), g::Base.RefValue{GpuCloudKey}, x::LweOperand, y::LweOperand, z::LweOperand) =
+    run_gate(g[], MUX, x, y, z)
 
-# not bootstrapped (src/gates.jl:76-93): cheap on the host, no device round trip needed
-gate_not(gck::GpuCloudKey, x::LweSample) = TFHE.LweSample(x.params, -x.a, -x.b, x.current_variance)
-gate_constant(gck::GpuCloudKey, value::Bool) =
-    TFHE.lwe_noiseless_trivial(TFHE.encode_message(value ? 1 : -1, 8), LweParams(gck.params.lwe_size))
+# not bootstrapped (src/gates.jl:76-93): on host samples no device round trip is needed
+gate_not(g::GpuCloudKey, x::LweSample) = -x
+gate_not(g::GpuCloudKey, xs::LweVec) = [-x for x in xs]
+gate_not(g::GpuCloudKey, d::GpuLweArray) = gates_on_device(g, NOT, (d,))
+broadcasted(::typeof(gate_not), g::GpuCloudKey, x::LweOperand) = gate_not(g, x)
+broadcasted(::typeof(gate_not), g::Base.RefValue{GpuCloudKey}, x::LweOperand) = gate_not(g[], x)
+
+gate_constant(g::GpuCloudKey, value::Bool) =
+    TFHE.lwe_noiseless_trivial(TFHE.encode_message(value ? 1 : -1, 8), LweParams(g.params.lwe_size))
+broadcasted(::typeof(gate_constant), g::GpuCloudKey, values::AbstractVector{Bool}) = [gate_constant(g, v) for v in values]
+broadcasted(::typeof(gate_constant), g::Base.RefValue{GpuCloudKey}, values::AbstractVector{Bool}) =
+    [gate_constant(g[], v) for v in values]
 
 # ---- multi-key (src/mk_api.jl:83-101, src/mk_gates.jl:7-12) ---------------------------------------------------
 # MKBootstrapKey.key[j, i] (bit j of party i) :: MKTransformedTGswExpSample with spectra x[l, P], y[l, P], c0[l],
@@ -199,6 +399,11 @@ function flatten_mk_spectra(bk, p::SchemeParameters, parties::Int)
     spectra
 end
 
+"""
+    GpuMKCloudKey(ck::MKCloudKey; device=0, devices=nothing)
+
+An `MKCloudKey` resident on the GPU(s); pass it to TFHE's own `mk_gate_nand` in place of the `MKCloudKey`.
+"""
 mutable struct GpuMKCloudKey
     params::SchemeParameters
     parties::Int
@@ -207,18 +412,25 @@ mutable struct GpuMKCloudKey
     function GpuMKCloudKey(ck::MKCloudKey; device::Integer=0, devices=nothing)
         p, P = ck.params, ck.parties
         ctx = create_context(p, devices === nothing ? [device] : devices)
-        spectra = flatten_mk_spectra(ck.bootstrap_key, p, P)
-        GC.@preserve spectra check(ctx, ccall((:tfhe_mk_load_bootstrap_key_c128, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Complex{Float64}}, Int32), ctx, spectra, Int32(P)))
-        # P single-key keyswitch keys back to back (src/mk_api.jl:97-98)
-        flat = cat([flatten_keyswitch_key(ks, p.lwe_size) for ks in ck.keyswitch_key]...; dims=5)
-        GC.@preserve flat check(ctx, ccall((:tfhe_mk_load_keyswitch_key, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Int32}, Int32), ctx, flat, Int32(P)))
         mck = new(p, P, ctx)
-        finalizer(g -> ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx), mck)
+        finalizer(destroy!, mck)
+        try
+            spectra = flatten_mk_spectra(ck.bootstrap_key, p, P)
+            GC.@preserve spectra check(ctx, ccall((:tfhe_mk_load_bootstrap_key_c128, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Complex{Float64}}, Int32), ctx, spectra, Int32(P)))
+            # P single-key keyswitch keys back to back (src/mk_api.jl:97-98)
+            flat = cat([flatten_keyswitch_key(ks, p.lwe_size) for ks in ck.keyswitch_key]...; dims=5)
+            GC.@preserve flat check(ctx, ccall((:tfhe_mk_load_keyswitch_key, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Int32}, Int32), ctx, flat, Int32(P)))
+        catch
+            destroy!(mck)
+            rethrow()
+        end
         mck
     end
 end
+
+broadcastable(m::GpuMKCloudKey) = Ref(m)
 
 # MKLweSample (src/mk_internals.jl:6-18: a is n x P, one column per party) <-> flat Int32[P*n+1] = a[:,1]; a[:,2]; ...; b
 function flatten(xs::AbstractVector{MKLweSample})
@@ -231,7 +443,10 @@ function flatten(xs::AbstractVector{MKLweSample})
     m
 end
 
-function mk_gate_nand(mck::GpuMKCloudKey, xs::AbstractVector{MKLweSample}, ys::AbstractVector{MKLweSample})
+const MKVec = AbstractVector{MKLweSample}
+
+function mk_nand_batch(mck::GpuMKCloudKey, xs::MKVec, ys::MKVec)
+    length(xs) == length(ys) || throw(DimensionMismatch("mk_gate_nand operands of lengths $(length(xs)) and $(length(ys))"))
     n, P, B = mck.params.lwe_size, mck.parties, length(xs)
     fx, fy = flatten(xs), flatten(ys)
     out = Array{Int32}(undef, n * P + 1, B)
@@ -242,6 +457,10 @@ function mk_gate_nand(mck::GpuMKCloudKey, xs::AbstractVector{MKLweSample}, ys::A
     [MKLweSample(params, reshape(out[1:n*P, g], n, P), out[n * P + 1, g], 0.) for g in 1:B]
 end
 
-mk_gate_nand(mck::GpuMKCloudKey, x::MKLweSample, y::MKLweSample) = mk_gate_nand(mck, [x], [y])[1]
+# methods on TFHE's mk_gate_nand (src/mk_gates.jl:7-12): scalar, vectors, and the batched form of its broadcast
+mk_gate_nand(mck::GpuMKCloudKey, x::MKLweSample, y::MKLweSample) = mk_nand_batch(mck, [x], [y])[1]
+mk_gate_nand(mck::GpuMKCloudKey, xs::MKVec, ys::MKVec) = mk_nand_batch(mck, xs, ys)
+broadcasted(::typeof(mk_gate_nand), mck::GpuMKCloudKey, xs::MKVec, ys::MKVec) = mk_nand_batch(mck, xs, ys)
+broadcasted(::typeof(mk_gate_nand), mck::Base.RefValue{GpuMKCloudKey}, xs::MKVec, ys::MKVec) = mk_nand_batch(mck[], xs, ys)
 
 end # module

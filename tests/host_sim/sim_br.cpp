@@ -170,8 +170,8 @@ double sim_blind_rotate(const int32_t *bara, int32_t n, int32_t L, int32_t log2_
     return worst;
 }
 
-// blind_rotate_kernel_v3's lane code (the shipped path): rotate_sub2 / load_digits2 / tw1f-folded passes /
-// untwist_add2, lane by lane.  bk spectra in engine order as sim_bk_prepare produces them.
+// blind_rotate_kernel_v3's lane code (the shipped path): rotate_sub3 on mirror-extended polynomial images /
+// load_digits2 / tw1f-folded passes / untwist_add2, lane by lane.  bk spectra in engine order as sim_bk_prepare produces them.
 double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t log2_base, int32_t mu,
                            const double *bk_spec, int32_t *ext)
 {
@@ -179,16 +179,22 @@ double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t lo
     const Gadget g = make_gadget(L, log2_base);
     const int32_t xormask = gadget_xor_mask(L, log2_base);
     const int K1 = 2;
-    std::vector<int32_t> acc_lds(K1 * kN);
+    constexpr int kImg = kMir + kN;                 // one polynomial image: mirror | coefficients
+    std::vector<int32_t> acc_lds(K1 * kImg);
     const cplx *bk = reinterpret_cast<const cplx *>(bk_spec);
     static LaneTw tw[64];
     for (int l = 0; l < 64; l++) load_lane_tw(l, T, tw[l]);
     double worst = 0.0;
     const int barb = bara[n] & (2 * kN - 1);
-    for (int j = 0; j < kN; j++) {
-        acc_lds[j] = 0;
-        const int idx = (j + barb) & (2 * kN - 1);
-        acc_lds[kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)mu) : mu;
+    for (int l = 0; l < 64; l++) {
+        int32_t z[16], b[16];
+        for (int m = 0; m < 16; m++) {
+            z[m] = 0;
+            const int idx = (l + 64 * m + barb) & (2 * kN - 1);
+            b[m] = (idx & kN) ? (int32_t)(0u - (uint32_t)mu) : mu;
+        }
+        store_cur<16>(l, z, acc_lds.data());
+        store_cur<16>(l, b, acc_lds.data() + kImg);
     }
     std::vector<cplx> xch(kXchElems);
     for (int i = 0; i < n; i++) {
@@ -202,8 +208,8 @@ double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t lo
             static int32_t temp[64][16];
             for (int l = 0; l < 64; l++) {
                 int32_t cur[16];
-                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + l + 64 * m];
-                rotate_sub2(l, a, acc_lds.data() + c * kN, cur, g.offset, xormask, temp[l]);
+                load_cur<16>(l, acc_lds.data() + c * kImg, cur);
+                rotate_sub3<16>(l, a, acc_lds.data() + c * kImg, cur, g.offset, xormask, temp[l]);
             }
             for (int p = 1; p <= L; p++) {
                 Regs x;
@@ -227,15 +233,16 @@ double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t lo
             for (int l = 0; l < 64; l++) {
                 inv2_pass_a(out[co][l], tw[l]);
                 int32_t accr[16];
-                for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + l + 64 * m];
+                load_cur<16>(l, acc_lds.data() + co * kImg, accr);
                 untwist_add2<true>(out[co][l], accr, &worst);
-                for (int m = 0; m < 16; m++) acc_lds[co * kN + l + 64 * m] = accr[m];
+                store_cur<16>(l, accr, acc_lds.data() + co * kImg);
             }
         }
     }
-    ext[0] = acc_lds[0];
-    for (int j = 1; j < kN; j++) ext[kN - j] = (int32_t)(0u - (uint32_t)acc_lds[j]);
-    ext[kN] = acc_lds[kN];
+    const int32_t *a0 = acc_lds.data() + kMir, *b0 = acc_lds.data() + kImg + kMir;
+    ext[0] = a0[0];
+    for (int j = 1; j < kN; j++) ext[kN - j] = (int32_t)(0u - (uint32_t)a0[j]);
+    ext[kN] = b0[0];
     return worst;
 }
 

@@ -131,7 +131,7 @@ def test_edge_cases_and_errors(tfhe, keys80, eng80):
         tfhe.Engine(K.params, 99)                            # no such device
 
 
-@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
+@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8,tw2reg>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
 def test_full_batch_properties(tfhe, orc, keys80, eng80, B, kernel):
     """BASELINE config 2 size (4096: two rounds of the one-wave kernel) and the chip-filling sizes of the two-wave kernel
     (1024: four workgroups on every CU, the waves of a workgroup swapping LDS buffers every step; 700: partly filled):

@@ -352,6 +352,57 @@ TFHE_HD void rotate_sub2(int lane, int a_mod_2N, const int32_t *acc_lds, const i
         temp[m] = (int32_t)((((uint32_t)v ^ sgn) + w) ^ (uint32_t)xormask);
     }
 }
+// ---- rotation with wave-uniform signs --------------------------------------------------------------------------
+// A blind rotation's exponent a is the same for every lane of a wave.  Split a = 64 qa + ra: coefficient lane + 64 m of
+// X^a acc is +-acc[(lane - ra) + 64 b] with b = (m - qa) mod NBLK and the sign bit NBLK of (m - qa) — both the same for
+// all lanes — except that a lane with lane < ra reaches below block 0 when b = 0: it wants block NBLK - 1 with the
+// opposite sign.  The LDS image of a polynomial therefore carries, in front of its N coefficients, a 64-word "mirror"
+// holding -acc[N - 64 + t]: the one address formula (lane - ra + 64 + 64 b words into the image) and the one scalar sign
+// then serve every lane.  Per coefficient that is an address add, a subtract, one v_xad_u32 ((v ^ sgn) + k) and the
+// digit-sign xor — 4 vector instructions where rotate_sub2 (per-lane wrap and sign) takes 9; block offsets, signs and
+// the offset constants live in scalar registers.  The mirror costs one extra LDS store per polynomial update.
+constexpr int kMir = 64;                   // words in front of the coefficients
+template <int NBLK>                        // NBLK = N / 64: 16 (N = 1024) or 32 (N = 2048)
+TFHE_HD void rotate_sub3(int lane, int a_mod_2N /* wave-uniform */, const int32_t *img /* mirror | N coefficients */,
+                         const int32_t (&cur)[NBLK], int32_t offset, int32_t xormask, int32_t (&temp)[NBLK])
+{
+    const int ra = a_mod_2N & 63, qa = a_mod_2N >> 6;
+    const int32_t *p = img + (lane - ra + kMir);
+#pragma unroll
+    for (int m = 0; m < NBLK; m++) {
+        const int B = (m - qa) & (2 * NBLK - 1);
+        const uint32_t sgn = (B & NBLK) ? 0xFFFFFFFFu : 0u;
+        const uint32_t v = (uint32_t)p[(B & (NBLK - 1)) * 64];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (left to itself the compiler splits this into xor / sub / add3 / xor with the sign bit extracted twice)
+        uint32_t c_s = (uint32_t)offset - sgn;                      // scalar
+        asm("" : "+s"(c_s));
+        const uint32_t k = c_s - (uint32_t)cur[m];
+        uint32_t r;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(sgn), "v"(k));
+        temp[m] = (int32_t)(r ^ (uint32_t)xormask);
+#else
+        const uint32_t k = ((uint32_t)offset - sgn) - (uint32_t)cur[m];
+        temp[m] = (int32_t)(((v ^ sgn) + k) ^ (uint32_t)xormask);
+#endif
+    }
+}
+// this lane's coefficients lane + 64 m of a polynomial image
+template <int NBLK>
+TFHE_HD void load_cur(int lane, const int32_t *img, int32_t (&cur)[NBLK])
+{
+#pragma unroll
+    for (int m = 0; m < NBLK; m++) cur[m] = img[kMir + lane + 64 * m];
+}
+// ... and back, refreshing the mirror (the lane's last coefficient is acc[N - 64 + lane])
+template <int NBLK>
+TFHE_HD void store_cur(int lane, const int32_t (&acc)[NBLK], int32_t *img)
+{
+#pragma unroll
+    for (int m = 0; m < NBLK; m++) img[kMir + lane + 64 * m] = acc[m];
+    img[lane] = (int32_t)(0u - (uint32_t)acc[NBLK - 1]);
+}
+
 // digit p (1-based) of a prepared coefficient: signed bit-field extract of bits [32 - p beta, 32 - (p-1) beta)
 TFHE_HD int32_t digit2(int32_t t, int p, int log2_base)
 {

@@ -103,6 +103,7 @@ __device__ __forceinline__ void wave_priority_step(int step, int prio_steps)
     else if (step == prio_steps) __builtin_amdgcn_s_setprio(0);
 }
 
+#ifdef TFHE_BUILD_BASELINE      // round-1 baseline (one wave per rotation, barriers, twiddles from global memory): A/B builds only
 template <int K1>
 __device__ __forceinline__ void store_acc(int lane, const int32_t (&acc)[16], int32_t *acc_lds)
 {
@@ -208,18 +209,80 @@ __global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
     if (lane == 0) ext[(K1 - 1) * kN] = acc[K1 - 1][0];
 }
 
+#endif  // TFHE_BUILD_BASELINE
+
 // Wave-private LDS hand-off: LDS instructions of one wave execute in issue order, so a compiler-level
 // fence is all a single-wave workgroup needs between a ds_write and the ds_read of another lane's data.
 #define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
+
+// One polynomial of an accumulator in LDS: mirror | N coefficients (rotate_sub3, br_core.hpp).
+constexpr int kImg = kMir + kN;
+
+// rotates polynomial image `img` by X^a (a wave-uniform) and subtracts it: temp = ((X^a - 1) acc + offset) ^ xormask.
+// `a` is pinned to a scalar register and made opaque so that the per-block offsets / signs are recomputed (on the scalar
+// unit) for every polynomial instead of being kept alive across the transforms.
+template <int NBLK>
+__device__ __forceinline__ void rotate_poly(int lane, int a, const int32_t *img, int32_t offset, int32_t xormask, int32_t (&temp)[NBLK])
+{
+    int32_t cur[NBLK];
+    load_cur<NBLK>(lane, img, cur);
+    int a_here = __builtin_amdgcn_readfirstlane(a);
+    asm volatile("" : "+s"(a_here));
+#ifdef TFHE_ABL_ROT      // timing experiment only (wrong results): no rotated reads
+    for (int m = 0; m < NBLK; m++) temp[m] = cur[m] ^ a_here;
+#else
+    rotate_sub3<NBLK>(lane, a_here, img, cur, offset, xormask, temp);
+#endif
+}
+// acc += round(untwisted y), image updated in place (mirror included)
+template <bool MARGIN>
+__device__ __forceinline__ void accumulate_poly(int lane, const cplx (&y)[8], int32_t *img, double *worst)
+{
+    int32_t accr[16];
+    load_cur<16>(lane, img, accr);
+    untwist_add2<MARGIN>(y, accr, worst);
+    store_cur<16>(lane, accr, img);
+}
+// accum = (0, ..., 0, X^{-barb} * (mu, ..., mu))     bootstrap.jl:54-56,78 ; tlwe.jl:77-81
+__device__ __forceinline__ void init_body_poly(int lane, int barb, int32_t mu, int32_t *img)
+{
+    int32_t b[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+        b[m] = (idx & kN) ? (int32_t)(0u - (uint32_t)mu) : mu;
+    }
+    store_cur<16>(lane, b, img);
+}
+__device__ __forceinline__ void init_zero_poly(int lane, int32_t *img)
+{
+    int32_t z[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) z[m] = 0;
+    store_cur<16>(lane, z, img);
+}
+// tlwe_extract_sample of one mask polynomial (tlwe.jl:55-59): a'[0] = p[0], a'[m] = -p[N-m]
+__device__ __forceinline__ void extract_mask_poly(int lane, const int32_t *img, int32_t *ext)
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int j = lane + 64 * m;
+        const int32_t v = img[kMir + j];
+        if (j == 0) ext[0] = v;
+        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
+    }
+}
 
 // v3: one wave per blind rotation at 2 waves/SIMD (<= 256 VGPRs, no AGPR/scratch spills).
 //   * pass-A twiddles (with the lane part of the twist folded in) resident in registers, pass-B twiddles
 //     in a 1 KB wave-private LDS table, the register part of the twist as compile-time constants:
 //     no global loads on the critical path except the key;
-//   * the accumulator lives only in LDS (read at rotate time and at the final add);
+//   * the accumulator lives only in LDS (read at rotate time and at the final add), each polynomial with its mirror
+//     block so that the rotation's signs and block offsets are scalar (rotate_sub3);
 //   * key spectra of the next transform prefetched into registers while the current FFT runs;
 //   * no s_barrier: wave-private LDS needs only compiler-level ordering;
-//   * no branch on bara[i] == 0 (the step then adds exactly zero).
+//   * no branch on bara[i] == 0 (the step then adds exactly zero);
+//   * the first transform of a step writes the spectrum accumulators (a product, not a multiply-add): no zeroing.
 template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */,
           bool MARGIN = false /* diagnostics: rounding margin + in-kernel clock (DiagArgs) */>
 __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
@@ -235,8 +298,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [kXchElems]
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][kImg]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [kXchElems]
     cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
@@ -253,15 +316,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
 #pragma unroll
         for (int q = 1; q < 8; q++) tw2r[q] = P.T.tw2[q * 8 + (lane & 7)];
     }
-    {
-        const int barb = bara[P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            acc_lds[lane + 64 * m] = 0;
-            acc_lds[kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    init_zero_poly(lane, acc_lds);
+    init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_lds + kImg);
     WAVE_LDS_FENCE();
 
     double worst = 0.0;
@@ -284,119 +340,142 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         wave_priority_step(i, P.prio_steps);
 
         cplx out[K1][8];
-#pragma unroll
-        for (int c = 0; c < K1; c++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
-
         int32_t temp[16];
 #pragma unroll 1
         for (int f = 0; f < F; f++) {
             const int c = f / L, p = f % L;        // component, digit index (0-based)
-            if (p == 0) {
-                int32_t cur[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
-                int a_here = a;
-                asm volatile("" : "+v"(a_here));   // keeps the 32 rotate addresses/signs from being hoisted out of the f loop
-                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
-            }
+            if (p == 0) rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
             cplx x[8];
             load_digits2(temp, p + 1, beta, x);
             // pass A
             dft8<false>(x);
 #pragma unroll
             for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
+#ifndef TFHE_ABL_X1
             x1_store_a(lane, x, xch);
             WAVE_LDS_FENCE();
             x1_load_b(lane, x, xch);
+#endif
             // pass B (twiddles from the LDS table)
             {
                 cplx t2[8];
 #pragma unroll
+#ifdef TFHE_ABL_TW2
+                for (int q = 1; q < 8; q++) t2[q] = tw1f[q];
+#else
                 for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
+#endif
                 dft8<false>(x);
 #pragma unroll
                 for (int q = 1; q < 8; q++) x[q] = cmul(x[q], t2[q]);
             }
             WAVE_LDS_FENCE();
+#ifndef TFHE_ABL_X2
             x2_store(lane, x, xch);
+#endif
             WAVE_LDS_FENCE();
             cplx k1v[8];
+#ifdef TFHE_ABL_KEY
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) { k1v[k2] = kbuf[k2]; asm volatile("" : "+v"(k1v[k2].x), "+v"(k1v[k2].y)); }
+#else
             if (KPF == 8 && KMID > 0) {
                 const cplx *kp = key_ptr(i, f);
 #pragma unroll
                 for (int k2 = 0; k2 < KMID; k2++) k1v[k2] = kp[(8 + k2) * 64];
                 WAVE_LDS_FENCE();
             }
+#endif
+#ifndef TFHE_ABL_X2
             x2_load(lane, x, xch);
+#endif
             WAVE_LDS_FENCE();
             dft8<false>(x);
-            // MAC: out[co] += D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128)
+            // MAC: out[co] (+)= D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128); f is wave-uniform: a scalar branch
             if (KPF == 16) {
+                if (f == 0) {
 #pragma unroll
-                for (int co = 0; co < K1; co++)
+                    for (int co = 0; co < K1; co++)
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
+                        for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cmul(x[k2], kbuf[co * 8 + k2]);
+                } else {
+#pragma unroll
+                    for (int co = 0; co < K1; co++)
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
+                }
             } else {
+#ifndef TFHE_ABL_KEY
                 const cplx *kp = key_ptr(i, f);
 #pragma unroll
                 for (int k2 = KMID; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
+#endif
+                if (f == 0) {
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kbuf[k2], out[0][k2]);
+                    for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cmul(x[k2], kbuf[k2]);
 #pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], k1v[k2], out[1][k2]);
+                    for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cmul(x[k2], k1v[k2]);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kbuf[k2], out[0][k2]);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], k1v[k2], out[1][k2]);
+                }
             }
             // prefetch the next transform's key
             {
                 const bool last = (f + 1 == F);
                 // (unconditional: on the very last transform this re-reads a valid chunk; a conditional
                 //  prefetch doubles the register pressure through the phi of old and new values)
+#ifndef TFHE_ABL_KEY
                 const cplx *kp = last ? key_ptr(i + 1 < P.n ? i + 1 : i, 0) : key_ptr(i, f + 1);
 #pragma unroll
                 for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
+#else
+                (void)last;
+#pragma unroll
+                for (int j = 0; j < KPF; j++) asm volatile("" : "+v"(kbuf[j].x), "+v"(kbuf[j].y));
+#endif
             }
         }
 #pragma unroll
         for (int co = 0; co < K1; co++) {
             dft8<true>(out[co]);
+#ifndef TFHE_ABL_X2
             x2_store(lane, out[co], xch);
             WAVE_LDS_FENCE();
             x2_load(lane, out[co], xch);
+#endif
             {
                 cplx t2[8];
 #pragma unroll
+#ifdef TFHE_ABL_TW2
+                for (int q = 1; q < 8; q++) t2[q] = tw1f[q];
+#else
                 for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
+#endif
 #pragma unroll
                 for (int q = 1; q < 8; q++) out[co][q] = cmulc(out[co][q], t2[q]);
             }
             dft8<true>(out[co]);
             WAVE_LDS_FENCE();
+#ifndef TFHE_ABL_X1
             x1_store_b(lane, out[co], xch);
             WAVE_LDS_FENCE();
             x1_load_a(lane, out[co], xch);
+#endif
             WAVE_LDS_FENCE();
 #pragma unroll
             for (int q = 0; q < 8; q++) out[co][q] = cmulc(out[co][q], tw1f[q]);
             dft8<true>(out[co]);
-            int32_t accr[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) accr[m] = acc_lds[co * kN + lane + 64 * m];
-            untwist_add2<MARGIN>(out[co], accr, &worst);
-            store_acc<K1>(lane, accr, acc_lds + co * kN);
+            accumulate_poly<MARGIN>(lane, out[co], acc_lds + co * kImg, &worst);
         }
         WAVE_LDS_FENCE();
     }
 
     int32_t *ext = P.ext + w * (kN + 1);
-#pragma unroll
-    for (int m = 0; m < 16; m++) {
-        const int j = lane + 64 * m;
-        const int32_t v = acc_lds[j];
-        if (j == 0) ext[0] = v;
-        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
-    }
-    if (lane == 0) ext[kN] = acc_lds[kN];
+    extract_mask_poly(lane, acc_lds, ext);
+    if (lane == 0) ext[kN] = acc_lds[kImg + kMir];
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
@@ -501,14 +580,7 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
 #pragma unroll
         for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
             int32_t temp[16];
-            {
-                int32_t cur[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
-                int a_here = a;
-                asm volatile("" : "+v"(a_here));
-                rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
-            }
+            rotate_poly<16>(lane, a, acc_lds + s * kImg, P.g.offset, xormask, temp);
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
                 // key polys for this transform (mk_internals.jl:371-385); the two every source needs are requested
@@ -546,11 +618,7 @@ __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, cons
 #pragma unroll
         for (int d = 0; d <= NP; d++) {
             fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
-            int32_t accr[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-            untwist_add2<MARGIN>(out[d], accr, &worst);
-            store_acc<2>(lane, accr, acc_lds + d * kN);
+            accumulate_poly<MARGIN>(lane, out[d], acc_lds + d * kImg, &worst);
         }
         WAVE_LDS_FENCE();
     }
@@ -564,8 +632,8 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kN * 4);          // [kXchElems]
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][kImg]
+    cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kImg * 4);        // [kXchElems]
     cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
@@ -576,16 +644,10 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     tw2_lds[lane] = P.T.tw2[lane];
-    {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
-        const int barb = bara[NP * P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            acc_lds[lane + 64 * m] = 0;
-            acc_lds[kN + lane + 64 * m] = 0;
-            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
+    init_zero_poly(lane, acc_lds);
+    init_zero_poly(lane, acc_lds + kImg);
+    init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
     WAVE_LDS_FENCE();
     // party-major double loop (mk_internals.jl:475-476)
     mk_party_steps<L, 0, MARGIN>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask, worst);
@@ -594,15 +656,8 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
 #pragma unroll
-    for (int c = 0; c < NP; c++)
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int jj = lane + 64 * m;
-            const int32_t v = acc_lds[c * kN + jj];
-            if (jj == 0) ext[c * kN] = v;
-            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
-        }
-    if (lane == 0) ext[NP * kN] = acc_lds[NP * kN];
+    for (int c = 0; c < NP; c++) extract_mask_poly(lane, acc_lds + c * kImg, ext + c * kN);
+    if (lane == 0) ext[NP * kN] = acc_lds[NP * kImg + kMir];
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
@@ -649,14 +704,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
             constexpr int s = job == 0 ? (WV == 0 ? PARTY : NP) : OTHER;      // source polynomial
             constexpr int p_begin = job == 0 ? 0 : WV * (L / 2), p_end = job == 0 ? L : (WV + 1) * (L / 2);
             int32_t temp[16];
-            {
-                int32_t cur[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
-                int a_here = a;
-                asm volatile("" : "+v"(a_here));
-                rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
-            }
+            rotate_poly<16>(lane, a, acc_lds + s * kImg, P.g.offset, xormask, temp);
             STAMP(0);
 #pragma unroll 1
             for (int p = p_begin; p < p_end; p++) {
@@ -725,11 +773,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
         STAMP(6);
         auto finish = [&](cplx (&o)[8], int d) {
             fft_inv_wave(lane, o, tw1f, tw2_lds, xch_oth);
-            int32_t accr[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-            untwist_add2<MARGIN>(o, accr, &worst);
-            store_acc<2>(lane, accr, acc_lds + d * kN);
+            accumulate_poly<MARGIN>(lane, o, acc_lds + d * kImg, &worst);
         };
         if (WV == 0) { finish(out[0], 0); finish(out[1], 1); }
         else finish(out[NP], NP);
@@ -753,9 +797,9 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 1, tid_r = tid & 127;
     const int rot = tid >> 7;                                                    // rotation within the workgroup
-    constexpr size_t kRotBytes = (NP + 1) * kN * 4 + (2 * kXchElems + kM) * sizeof(cplx);
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);      // [NP+1][N]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + (NP + 1) * kN * 4);   // [2 waves][kXchElems]
+    constexpr size_t kRotBytes = (NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);      // [NP+1][kImg]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + (NP + 1) * kImg * 4);   // [2 waves][kXchElems]
     cplx *extra = xch_all + 2 * kXchElems;                                       // [512] second hand-off slot of wave 1
     cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);             // [8][8]
     cplx *xch_own = xch_all + wv * kXchElems, *xch_oth = xch_all + (1 - wv) * kXchElems;
@@ -769,15 +813,9 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
-    {   // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
-        const int barb = bara[NP * P.n] & (2 * kN - 1);
-        for (int j = tid_r; j < kN; j += 128) {
-            const int idx = (j + barb) & (2 * kN - 1);
-            acc_lds[j] = 0;
-            acc_lds[kN + j] = 0;
-            acc_lds[2 * kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
+    if (wv == 0) { init_zero_poly(lane, acc_lds); init_zero_poly(lane, acc_lds + kImg); }
+    else init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
     __syncthreads();
     wave_priority_begin(P.prio_steps);
     // party-major double loop (mk_internals.jl:475-476)
@@ -792,13 +830,8 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
-    for (int jj = tid_r; jj < NP * kN; jj += 128) {
-        const int c = jj >> 10, j1 = jj & (kN - 1);
-        const int32_t v = acc_lds[jj];
-        if (j1 == 0) ext[c * kN] = v;
-        else ext[c * kN + kN - j1] = (int32_t)(0u - (uint32_t)v);
-    }
-    if (tid_r == 0) ext[NP * kN] = acc_lds[NP * kN];
+    extract_mask_poly(lane, acc_lds + wv * kImg, ext + wv * kN);                  // wave c extracts mask column c
+    if (tid_r == 0) ext[NP * kN] = acc_lds[NP * kImg + kMir];
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
@@ -836,10 +869,10 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
     double worst = 0.0;
     const int lane = threadIdx.x & 63, rot = threadIdx.x >> 6;
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
-    const size_t rot_bytes = (ACCG ? 0 : (size_t)(NP + 1) * kN * 4) + (kXchElems + 64) * sizeof(cplx);
-    int32_t *acc_lds = ACCG ? P.acc + w_raw * (size_t)(NP + 1) * kN                  // [NP+1][N] (the name stays: LDS in the default build)
+    const size_t rot_bytes = (ACCG ? 0 : (size_t)(NP + 1) * kImg * 4) + (kXchElems + 64) * sizeof(cplx);
+    int32_t *acc_lds = ACCG ? P.acc + w_raw * (size_t)(NP + 1) * kImg                // [NP+1][kImg] (the name stays: LDS in the default build)
                             : reinterpret_cast<int32_t *>(smem + rot * rot_bytes);
-    cplx *xch = reinterpret_cast<cplx *>(smem + rot * rot_bytes + (ACCG ? 0 : (size_t)(NP + 1) * kN * 4));
+    cplx *xch = reinterpret_cast<cplx *>(smem + rot * rot_bytes + (ACCG ? 0 : (size_t)(NP + 1) * kImg * 4));
     cplx *tw2_lds = xch + kXchElems;
     const bool live = w_raw < (size_t)P.R;                                   // a padding rotation repeats the last one, stores nothing
     const size_t w = live ? w_raw : (size_t)P.R - 1;
@@ -852,17 +885,8 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     tw2_lds[lane] = P.T.tw2[lane];
-    {
-        const int barb = bara[(size_t)NP * P.n] & (2 * kN - 1);
-        for (int s = 0; s < NP; s++)
-#pragma unroll
-            for (int m = 0; m < 16; m++) acc_lds[s * kN + lane + 64 * m] = 0;
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            acc_lds[NP * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    for (int s = 0; s < NP; s++) init_zero_poly(lane, acc_lds + s * kImg);
+    init_body_poly(lane, bara[(size_t)NP * P.n] & (2 * kN - 1), P.mu, acc_lds + NP * kImg);
     auto acc_fence = [&]() {
         if (ACCG) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -875,11 +899,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
 
     auto finish = [&](cplx (&o)[8], int d) {      // inverse transform, round, add into accumulator polynomial d
         fft_inv_wave(lane, o, tw1f, tw2_lds, xch);
-        int32_t accr[16];
-#pragma unroll
-        for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-        untwist_add2<MARGIN>(o, accr, &worst);
-        store_acc<2>(lane, accr, acc_lds + d * kN);
+        accumulate_poly<MARGIN>(lane, o, acc_lds + d * kImg, &worst);
     };
 
 #pragma unroll 1
@@ -898,14 +918,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
 #pragma unroll
                 for (int q = 0; q < 8; q++) o_self[q] = mk(0.0, 0.0);
                 int32_t temp[16];
-                {
-                    int32_t cur[16];
-#pragma unroll
-                    for (int m = 0; m < 16; m++) cur[m] = acc_lds[s * kN + lane + 64 * m];
-                    int a_here = a;
-                    asm volatile("" : "+v"(a_here));   // keeps the 32 rotate addresses / signs from being hoisted out of the source loop
-                    rotate_sub2(lane, a_here, acc_lds + s * kN, cur, P.g.offset, xormask, temp);
-                }
+                rotate_poly<16>(lane, a, acc_lds + s * kImg, P.g.offset, xormask, temp);
 #pragma unroll 1
                 for (int p = 0; p < L; p++) {
                     const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]
@@ -945,15 +958,8 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
     if (!live) return;
 
     int32_t *ext = P.ext + w * ((size_t)NP * kN + 1);
-    for (int c = 0; c < NP; c++)
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int jj = lane + 64 * m;
-            const int32_t v = acc_lds[c * kN + jj];
-            if (jj == 0) ext[(size_t)c * kN] = v;
-            else ext[(size_t)c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
-        }
-    if (lane == 0) ext[(size_t)NP * kN] = acc_lds[NP * kN];
+    for (int c = 0; c < NP; c++) extract_mask_poly(lane, acc_lds + c * kImg, ext + (size_t)c * kN);
+    if (lane == 0) ext[(size_t)NP * kN] = acc_lds[NP * kImg + kMir];
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, lane == 0);
 }
 
@@ -978,12 +984,12 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                // [2][kXchElems]: the waves swap them every step
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [2][kXchElems]: the waves swap them every step
     cplx *tw2_lds = xch_all + 2 * kXchElems;                                     // [8][8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = tid >> 6;                                                     // wave = owned polynomial
-    int32_t *acc_lds = acc_all + wv * kN;
+    int32_t *acc_lds = acc_all + wv * kImg;
     const size_t w = blockIdx.x;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
@@ -993,15 +999,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
-    {
-        const int barb = bara[P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            const int32_t body = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-            acc_lds[lane + 64 * m] = wv ? body : 0;
-        }
-    }
+    if (wv) init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_lds);
+    else init_zero_poly(lane, acc_lds);
     __syncthreads();
     STAMP_DECL;
 
@@ -1023,12 +1022,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
 #pragma unroll
         for (int q = 0; q < 8; q++) { own[q] = mk(0.0, 0.0); oth[q] = mk(0.0, 0.0); }
         int32_t temp[16];
-        {
-            int32_t cur[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
-            rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
-        }
+        rotate_poly<16>(lane, a, acc_lds, P.g.offset, xormask, temp);
         STAMP(0);
 #pragma unroll 1
         for (int p = 0; p < L; p++) {
@@ -1062,11 +1056,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
         STAMP(5);
         fft_inv_wave(lane, own, tw1f, tw2_lds, xch_next);
         STAMP(6);
-        int32_t accr[16];
-#pragma unroll
-        for (int m = 0; m < 16; m++) accr[m] = acc_lds[lane + 64 * m];
-        untwist_add2<MARGIN>(own, accr, &worst);
-        store_acc<2>(lane, accr, acc_lds);
+        accumulate_poly<MARGIN>(lane, own, acc_lds, &worst);
         WAVE_LDS_FENCE();
         STAMP(7);
     }
@@ -1074,17 +1064,8 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     __syncthreads();
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN + 1);
-    if (wv == 0) {
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int j = lane + 64 * m;
-            const int32_t v = acc_all[j];
-            if (j == 0) ext[0] = v;
-            else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
-        }
-    } else if (lane == 0) {
-        ext[kN] = acc_all[kN];
-    }
+    if (wv == 0) extract_mask_poly(lane, acc_all, ext);
+    else if (lane == 0) ext[kN] = acc_all[kImg + kMir];
 }
 
 // ---- smallest batches: every transform split over two waves ------------------------------------------
@@ -1193,14 +1174,14 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][N]
-    cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kN * 4);                 // [W][kH2Buf]
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg]
+    cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);               // [W][kH2Buf]
     cplx *extra_all = tb_all + W * kH2Buf;                                       // [W][256]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = tid >> 6;                                                     // wave = (p, c, h): owners (p = 0) are waves 0..3, one per SIMD
     const int h = wv & 1, c = (wv >> 1) & 1, p = wv >> 2;
     const bool owner = (p == 0);                                                 // owns half h of output component co = c
-    int32_t *acc_lds = acc_all + c * kN;
+    int32_t *acc_lds = acc_all + c * kImg;
     cplx *tb = tb_all + wv * kH2Buf, *extra = extra_all + wv * 256;
     const size_t w = blockIdx.x;
     const int32_t *bara = P.bara + w * (P.n + 1);
@@ -1215,14 +1196,8 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         tw.tw2[q] = HT.tw2q[q * 16 + (lane & 15)];
         tw.tw3[q] = HT.tw3q[q * 4 + (lane & 3)];
     }
-    {
-        const int barb = bara[P.n] & (2 * kN - 1);
-        for (int j = tid; j < kN; j += 256 * L) {
-            const int idx = (j + barb) & (2 * kN - 1);
-            acc_all[j] = 0;
-            acc_all[kN + j] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    if (wv == 0) init_zero_poly(lane, acc_all);
+    else if (wv == 1) init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_all + kImg);
     __syncthreads();
 
     // this lane's four frequencies f = 2 k' + h, k' = q + 4 q2 + 16 q3 + 64 q4: in the key's (v3) order frequency f sits
@@ -1245,9 +1220,8 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         int32_t cur[16];                          // this lane's coefficients of polynomial c (an owner adds its half back at the end)
         {
             int32_t temp[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) cur[m] = acc_lds[lane + 64 * m];
-            rotate_sub2(lane, a, acc_lds, cur, P.g.offset, xormask, temp);
+            load_cur<16>(lane, acc_lds, cur);
+            rotate_sub3<16>(lane, __builtin_amdgcn_readfirstlane(a), acc_lds, cur, P.g.offset, xormask, temp);
             STAMP(0);
             cplx x8[8];
             load_digits2(temp, p + 1, beta, x8);      // (d[t+64r] - i d[t+64r+512]) e^{-i pi r/16}, r < 8
@@ -1326,8 +1300,11 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
                 }
                 const int jlo = lane + 64 * (R + 4 * h);
                 const int32_t clo = h ? cur[R + 4] : cur[R], chi = h ? cur[R + 12] : cur[R + 8];     // read at rotate time; nobody else writes them
-                acc_lds[jlo] = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
-                acc_lds[jlo + kM] = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+                const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
+                const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+                acc_lds[kMir + jlo] = nlo;
+                acc_lds[kMir + jlo + kM] = nhi;
+                if (h == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
             });
         }
         STAMP(8);
@@ -1337,12 +1314,8 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     if (wv < 4) STAMP_FLUSH(P.diag, wv);
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN + 1);
-    for (int j = tid; j < kN; j += 256 * L) {
-        const int32_t v = acc_all[j];
-        if (j == 0) ext[0] = v;
-        else ext[kN - j] = (int32_t)(0u - (uint32_t)v);
-    }
-    if (tid == 0) ext[kN] = acc_all[kN];
+    if (wv == 0) extract_mask_poly(lane, acc_all, ext);
+    else if (tid == 64) ext[kN] = acc_all[kImg + kMir];
 }
 
 // ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
@@ -1356,8 +1329,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][kImg]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);
     cplx *tw2_lds = xch + kXchElems;
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
@@ -1369,16 +1342,9 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     tw2_lds[lane] = P.T.tw2[lane];
-    {
-        const int barb = bara[P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            acc_lds[lane + 64 * m] = 0;
-            acc_lds[kN + lane + 64 * m] = 0;
-            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-    }
+    init_zero_poly(lane, acc_lds);
+    init_zero_poly(lane, acc_lds + kImg);
+    init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
     WAVE_LDS_FENCE();
 
     // (no wave_priority_* here: 22 KB of LDS per wave put 7 waves on a CU, so one SIMD has a single wave; measured 3 % slower with it)
@@ -1394,14 +1360,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll 1
         for (int c = 0; c < K1; c++) {
             int32_t temp[16];
-            {
-                int32_t cur[16];
-#pragma unroll
-                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
-                int a_here = a;
-                asm volatile("" : "+v"(a_here));
-                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
-            }
+            rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
@@ -1424,11 +1383,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll
         for (int d = 0; d < K1; d++) {
             fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
-            int32_t accr[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
-            untwist_add2<MARGIN>(out[d], accr, &worst);
-            store_acc<2>(lane, accr, acc_lds + d * kN);
+            accumulate_poly<MARGIN>(lane, out[d], acc_lds + d * kImg, &worst);
         }
         WAVE_LDS_FENCE();
     }
@@ -1436,15 +1391,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
     int32_t *ext = P.ext + w * (2 * kN + 1);
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int jj = lane + 64 * m;
-            const int32_t v = acc_lds[c * kN + jj];
-            if (jj == 0) ext[c * kN] = v;
-            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
-        }
-    if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
+    for (int c = 0; c < 2; c++) extract_mask_poly(lane, acc_lds + c * kImg, ext + c * kN);
+    if (lane == 0) ext[2 * kN] = acc_lds[2 * kImg + kMir];
 }
 
 // ---- N = 2048: two waves per blind rotation ----------------------------------------------------------
@@ -1495,18 +1443,7 @@ __device__ __forceinline__ cplx fwd_in_2048(double lo, double hi, double s2, dou
     return mk(re * cr - im * sr, -(re * sr + im * cr));          // (re - i im) e^{-i theta}
 }
 
-__device__ __forceinline__ void rotate_sub_2048(int lane, int a, const int32_t *acc_lds, int32_t offset, int32_t xormask, int32_t (&temp)[32])
-{
-    const int base = (lane - a) & (2 * kN2 - 1);
-#pragma unroll
-    for (int m = 0; m < 32; m++) {
-        const int idx = (base + 64 * m) & (2 * kN2 - 1);
-        const int32_t v = acc_lds[idx & (kN2 - 1)];
-        const int32_t cur = acc_lds[lane + 64 * m];
-        const uint32_t sgn = (idx & kN2) ? 0xFFFFFFFFu : 0u;
-        temp[m] = (int32_t)(((((uint32_t)v ^ sgn) - sgn) - (uint32_t)cur + (uint32_t)offset) ^ (uint32_t)xormask);
-    }
-}
+constexpr int kImg2 = kMir + kN2;       // one N = 2048 polynomial in LDS: mirror | coefficients (rotate_sub3<32>)
 
 // forward 512-point transform of this wave's half (after the radix-2 split), x in / spectrum out
 __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
@@ -1532,9 +1469,9 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, tid_r = tid & 127;              // tid_r: thread within its rotation
     const int rot = tid >> 7;                                                     // rotation within the workgroup
-    constexpr size_t kRotBytes = K1 * kN2 * 4 + 2 * kXchElems * sizeof(cplx);
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][2048]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kN2 * 4);   // [2 waves][kXchElems]
+    constexpr size_t kRotBytes = K1 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][kImg2]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kImg2 * 4);   // [2 waves][kXchElems]
     cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
     const bool wave1 = ((tid >> 6) & 1) != 0;                                     // wave-uniform
     cplx *xch = xch_all + (wave1 ? kXchElems : 0);
@@ -1551,13 +1488,15 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1 ? 512 : 0) + q * 64 + lane];
     if (tid < 64) tw2_lds[tid] = P.tw2[tid];
-    {
+    {   // wave 0 writes the (zero) mask polynomial, wave 1 the body X^{-barb} (mu, ..., mu), mirrors included
         const int barb = bara[P.n] & (2 * kN2 - 1);
-        for (int j = tid_r; j < kN2; j += 128) {
-            const int idx = (j + barb) & (2 * kN2 - 1);
-            acc_lds[j] = 0;
-            acc_lds[kN2 + j] = (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        int32_t v[32];
+#pragma unroll
+        for (int m = 0; m < 32; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN2 - 1);
+            v[m] = !wave1 ? 0 : (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
         }
+        store_cur<32>(lane, v, acc_lds + (wave1 ? kImg2 : 0));
     }
     __syncthreads();
     STAMP_DECL;
@@ -1578,11 +1517,7 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
 #pragma unroll 1
         for (int c = 0; c < K1; c++) {
             int32_t temp[32];
-            {
-                int a_here = a;
-                asm volatile("" : "+v"(a_here));
-                rotate_sub_2048(lane, a_here, acc_lds + c * kN2, P.g.offset, xormask, temp);
-            }
+            rotate_poly<32>(lane, a, acc_lds + c * kImg2, P.g.offset, xormask, temp);
             STAMP(0);
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
@@ -1668,14 +1603,16 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
                     worst = f2 > worst ? f2 : worst;
                     worst = f3 > worst ? f3 : worst;
                 }
-                const int jlo = lane + 64 * R;
+                const int jlo = kMir + lane + 64 * R;
                 ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
                 ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
                 ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
-                ap[jlo + 1536] = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
+                const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
+                ap[jlo + 1536] = last;
+                if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
             });
         };
-        if (wave1) finish(oth, out[1], acc_lds + kN2);
+        if (wave1) finish(oth, out[1], acc_lds + kImg2);
         else finish(out[0], oth, acc_lds);
         STAMP(8);
         __syncthreads();
@@ -1687,11 +1624,11 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
     int32_t *ext = P.ext + w * (kN2 + 1);
     for (int j = tid_r; j < kN2; j += 128) {
-        const int32_t v = acc_lds[j];
+        const int32_t v = acc_lds[kMir + j];
         if (j == 0) ext[0] = v;
         else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
     }
-    if (tid_r == 0) ext[kN2] = acc_lds[kN2];
+    if (tid_r == 0) ext[kN2] = acc_lds[kImg2 + kMir];
 }
 
 // key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024

@@ -79,8 +79,9 @@ struct tfhe_ctx {
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
     int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
-    int br_variant = 0;          // 0 = by decomposition length (default: 3 for l = 2, else 2), 1 = baseline kernel, 2 = v3 with the whole key chunk
-                                 // requested a transform ahead, 3 = v3 with half of it ahead and the rest inside / after the transform
+    int br_variant = 0;          // 0 = default (4), 1 = round-1 baseline kernel (-DTFHE_BUILD_BASELINE builds only), 2 = v3 with the whole key chunk
+                                 // requested a transform ahead, 3 = v3 with half of it ahead and the rest inside / after the transform,
+                                 // 4 = 3 with the pass-B twiddles in registers instead of a wave-private LDS table
 
     // tables
     cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
@@ -600,7 +601,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         b.R = (int32_t)R;
         // n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation per workgroup)
         const int rw = c->n2048_rw;
-        const size_t ldsb = (size_t)rw * (2 * kN2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
+        const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
 #define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
         do {                                                                                                       \
@@ -626,7 +627,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     if (c->P.k == 2) {
-        const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+        const size_t ldsk = 3 * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
 #define LAUNCH_K2(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, true>), dim3((unsigned)R), dim3(64), ldsk, s, a);  \
         else hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false>), dim3((unsigned)R), dim3(64), ldsk, s, a)
@@ -636,19 +637,23 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         name_kernel(c, "blind_rotate_kernel_k2<%d>", L);
         return TFHE_OK;
     }
-    const int brv = c->br_variant ? c->br_variant : (L == 2 ? 3 : 2);      // 0 = by decomposition length
+    const int brv = c->br_variant ? c->br_variant : 4;                     // 0 = default: half key chunk ahead + pass-B twiddles in registers
     if ((c->br_tiny >= 0 && (int64_t)R <= c->br_tiny) && brv >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
-        const size_t ldsh = 2 * kN * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx);
+        const size_t ldsh = 2 * kImg * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx);
 #define LAUNCH_H2_(LL, DG)                                                                                         \
         do {                                                                                                       \
             HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_h2<LL, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh)); \
             hipLaunchKernelGGL((blind_rotate_kernel_h2<LL, DG>), dim3((unsigned)R), dim3(256 * LL), ldsh, s, a, ht); \
         } while (0)
 #define LAUNCH_H2(LL) do { if (dg) LAUNCH_H2_(LL, true); else LAUNCH_H2_(LL, false); } while (0)
-        BR_CASES(LAUNCH_H2)
+        switch (L) {                       // l = 4 (16 waves of 128 registers: spills) is never selected and not instantiated
+        case 1: LAUNCH_H2(1); break;
+        case 2: LAUNCH_H2(2); break;
+        default: LAUNCH_H2(3); break;
+        }
 #undef LAUNCH_H2
 #undef LAUNCH_H2_
         HIP_TRY(c, hipGetLastError());
@@ -657,7 +662,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     }
     if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && brv >= 2) {
         // 27.4 KB of LDS and < 256 registers per wave: four workgroups per CU, 1024 rotations resident at two waves per SIMD
-        const size_t ldsw = 2 * kN * 4 + (2 * kXchElems + 64) * sizeof(cplx);
+        const size_t ldsw = 2 * kImg * 4 + (2 * kXchElems + 64) * sizeof(cplx);
 #define LAUNCH_W2(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, true>), dim3((unsigned)R), dim3(128), ldsw, s, a); \
         else hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false>), dim3((unsigned)R), dim3(128), ldsw, s, a)
@@ -668,19 +673,22 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     if (brv >= 2) {
-        const size_t lds3 = 2 * kN * 4 + (kXchElems + 64) * sizeof(cplx);
-        const bool half = (brv == 3);
+        const size_t lds3 = 2 * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
+        const bool half = (brv == 3 || brv == 4), t2r = (brv == 4);
 #define LAUNCH_V3(LL)                                                                                              \
-        if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
+        if (t2r && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
+        else if (t2r) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, false>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
+        else if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);   \
         else if (half) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
         else if (dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
         else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
         BR_CASES(LAUNCH_V3)
 #undef LAUNCH_V3
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
+        name_kernel(c, t2r ? "blind_rotate_kernel_v3<%d,%d,tw2reg>" : "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
         return TFHE_OK;
     }
+#ifdef TFHE_BUILD_BASELINE
     const size_t lds = 2 * kN * 4 + kXchElems * sizeof(cplx);
 #define LAUNCH_V1(LL) hipLaunchKernelGGL((blind_rotate_kernel<LL, 2>), dim3((unsigned)R), dim3(64), lds, s, a)
     BR_CASES(LAUNCH_V1)
@@ -689,6 +697,9 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     name_kernel(c, "blind_rotate_kernel<%d,2>", L);
     c->diag_rows = 0;      // the baseline kernel has no DIAG instantiation
     return TFHE_OK;
+#else
+    return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: br_variant 1 (round-1 baseline kernel) is compiled only with -DTFHE_BUILD_BASELINE");
+#endif
 }
 
 static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const int32_t *e1, const int32_t *dst,
@@ -1362,13 +1373,13 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     a.bara = (const int32_t *)c->bara.p; a.bk = c->d_mk_bk; a.ext = (int32_t *)c->ext.p; a.T = c->T; a.g = c->g;
     a.n = n; a.mu = (int32_t)(1u << 29); a.R = (int32_t)B;
     a.prio_steps = (int32_t)((int64_t)NP * n * c->br_prio_pct / 100);
-    const size_t lds = (size_t)(NP + 1) * kN * 4 + (kXchElems + 64) * sizeof(cplx);
+    const size_t lds = (size_t)(NP + 1) * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
     const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
     if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
         // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four)
         const int rw = c->mk_rw;
-        const size_t lds2 = (size_t)rw * ((NP + 1) * kN * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
+        const size_t lds2 = (size_t)rw * ((NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         a.R = (int32_t)B;
 #define LAUNCH_MK2(LL, DG, RWV)                                                                                    \
@@ -1409,7 +1420,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         ga.acc = nullptr;
         if (accg) {
-            HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kN * sizeof(int32_t)));
+            HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
             ga.acc = (int32_t *)c->mk_acc.p;
         }
 #define LAUNCH_MKG(DG, RWV)                                                                                        \
@@ -1630,7 +1641,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "br_variant")) {
-        if (value < 0 || value > 3) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 0 (by decomposition length), 1, 2 or 3");
+        if (value < 0 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 0 (by decomposition length), 1, 2, 3 or 4");
         c->br_variant = (int)value;
         return TFHE_OK;
     }
