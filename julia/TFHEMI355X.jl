@@ -247,7 +247,7 @@ function upload(g::GpuCloudKey, xs::AbstractVector{LweSample})
     isempty(xs) && return GpuLweArray(g, rows)
     flat = flatten(xs)
     first_fresh = isempty(rows) ? 0 : rows[1]
-    contiguous = all(rows[i] == first_fresh + i - 1 for i in 1:length(rows))
+    contiguous = rows == collect(Int32, first_fresh:(first_fresh + length(rows) - 1))
     if contiguous
         GC.@preserve flat check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
             (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}), g.ctx, first_fresh, length(rows), flat))

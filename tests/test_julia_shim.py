@@ -106,7 +106,7 @@ def test_every_ccall_matches_the_header():
     # the shim binds the whole single-key and multi-key path
     for need in ("tfhe_ctx_create", "tfhe_ctx_create_multi", "tfhe_load_bootstrap_key_c128", "tfhe_load_keyswitch_key", "tfhe_gates_batch",
                  "tfhe_mk_load_bootstrap_key_c128", "tfhe_mk_load_keyswitch_key", "tfhe_mk_gate_nand_batch", "tfhe_keygen_cloud_key",
-                 "tfhe_ctx_destroy", "tfhe_last_error"):
+                 "tfhe_ctx_destroy", "tfhe_last_error", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_gather", "tfhe_gates_level"):
         assert need in seen, need
 
 
@@ -127,3 +127,73 @@ def test_julia_blocks_and_brackets_balance():
         n_open = len(re.findall(openers, code))
         n_end = len(re.findall(r"\bend\b", code))
         assert n_open == n_end, f"{os.path.basename(path)}: {n_open} block openers, {n_end} `end`"
+
+
+# ---- the shim sits BEHIND the reference's exported names (it must extend TFHE's functions, not define namesakes) --------
+REF_EXPORTS = ["make_key_pair", "LweSample", "SecretKey", "CloudKey", "encrypt", "decrypt", "tfhe_parameters_80", "tfhe_parameters_128",
+               "gate_nand", "gate_or", "gate_and", "gate_xor", "gate_xnor", "gate_not", "gate_constant", "gate_nor", "gate_andny",
+               "gate_andyn", "gate_orny", "gate_oryn", "gate_mux", "SharedKey", "CloudKeyPart", "MKCloudKey", "mk_encrypt", "mk_decrypt",
+               "mktfhe_parameters_2party", "mktfhe_parameters_4party", "mktfhe_parameters_8party", "mk_gate_nand"]      # src/TFHE.jl:24-61
+GATES = [n for n in REF_EXPORTS if n.startswith("gate_")] + ["mk_gate_nand"]
+
+
+def _name_lists(src, keyword):
+    """Names listed after `keyword` statements (continuation lines end in a comma)."""
+    names = []
+    for m in re.finditer(r"^\s*" + keyword + r"\s+((?:[^\n]*,\s*\n)*[^\n]*)", src, flags=re.M):
+        body = m.group(1)
+        if ":" in body.split(",")[0]:
+            body = body.split(":", 1)[1]
+        names += [w.strip() for w in body.replace("\n", " ").split(",") if w.strip()]
+    return names
+
+
+def _reference_exports():
+    """The export list as the reference has it, when the checkout is there (it is not on the GPU box)."""
+    path = "/root/reference/src/TFHE.jl"
+    if not os.path.exists(path):
+        return None
+    return re.findall(r"^export\s+(\w+)", open(path).read(), flags=re.M)
+
+
+def test_reference_export_list_is_current():
+    ref = _reference_exports()
+    if ref is not None:
+        assert sorted(ref) == sorted(REF_EXPORTS)
+
+
+def test_shim_extends_the_references_functions():
+    src = strip_julia(open(JULIA[0]).read())
+    exported = _name_lists(src, "export")
+    imported = [n for n in _name_lists(src, "import") if re.fullmatch(r"\w+", n)]
+    assert "GpuCloudKey" in exported and "GpuMKCloudKey" in exported and "GpuLweArray" in exported
+    # a name the reference exports may be re-exported only if it was imported from TFHE (i.e. it is TFHE's own binding)
+    for name in exported:
+        if name in REF_EXPORTS:
+            assert name in imported, f"shim exports {name}, which TFHE exports too, without `import TFHE: {name}`: two bindings, unusable"
+    # every gate the reference exports gets methods on TFHE's function: imported, and never redefined as a new function first
+    m = re.search(r"import TFHE:\s*((?:[^\n]*,\s*\n)*[^\n]*)", src)
+    from_tfhe = [w.strip() for w in m.group(1).replace("\n", " ").split(",")]
+    for g in GATES:
+        assert g in from_tfhe, f"{g} is not imported from TFHE: a method definition would create a second function"
+
+
+def test_every_gate_has_a_batched_broadcast_method():
+    """gate_xor.(gck, c1, c2) (docs/src/manual.md:35) must be ONE GPU batch: a `broadcasted(::typeof(gate), g::GpuCloudKey, ...)`
+    method per exported gate (written out, or generated by the @eval loop over (name, opcode) pairs)."""
+    src = strip_julia(open(JULIA[0]).read())
+    looped = []
+    m = re.search(r"for \(fn, op\) in \(((?:.|\n)*?)\)\s*\n\s*@eval begin((?:.|\n)*?)\n\s*end\s*\n\s*end", src)
+    assert m, "the @eval loop over the two-input gates is gone"
+    names = re.findall(r":(\w+)", m.group(1))
+    body = m.group(2)
+    assert re.search(r"\$fn\(g::GpuCloudKey", body), "the loop no longer defines the scalar / vector methods"
+    if re.search(r"broadcasted\(::typeof\(\$fn\), g::GpuCloudKey", body):
+        looped = names
+    for g in GATES:
+        key = "GpuMKCloudKey" if g == "mk_gate_nand" else "GpuCloudKey"
+        explicit = re.search(r"broadcasted\(::typeof\(" + g + r"\), \w+::" + key, src)
+        assert g in looped or explicit, f"no batched broadcasted(::typeof({g}), ::{key}, ...) method"
+        method = g in names or re.search(r"^" + g + r"\(\w+::" + key, src, flags=re.M)
+        assert method, f"no {g}(::{key}, ...) method"
+    assert re.search(r"broadcastable\(\w+::GpuCloudKey\)", src) and re.search(r"broadcastable\(\w+::GpuMKCloudKey\)", src)
