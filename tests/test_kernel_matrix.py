@@ -80,7 +80,7 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     idx = [0, 1, 7, 8, 511, 512, 1023, 1024]
     want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8)
     for rows, kernel in ((8, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (9, f"blind_rotate_kernel_w2<{l}>"),
-                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, default_v3)):
+                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, f"blind_rotate_kernel_v3<{l},8,tw2reg>")):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
         sel = [j for j, r in enumerate(idx) if r < rows]
@@ -154,7 +154,7 @@ def test_mk_two_party_kernel_every_l(tfhe, orc, l):
 
 @pytest.mark.parametrize("which,parties,l,beta,n", [("4party", 4, 5, 6, 8), ("8party", 8, 8, 4, 4), ("3-of-4", 3, 5, 6, 8), ("2party-general", 2, 4, 7, 12)])
 def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
-    """mk_blind_rotate_kernel_general at the shipped 4- and 8-party decompositions (mk_api.jl:16-34: l = 5 / beta = 6,
+    """mk_blind_rotate_kernel_g2<P,l> and mk_blind_rotate_kernel_general at the shipped 4- and 8-party decompositions (mk_api.jl:16-34: l = 5 / beta = 6,
     l = 8 / beta = 4): up to (P+1) l products are summed in the spectrum domain before ONE rounding — the margin
     of exactly that is asserted on the GPU."""
     p, rng, sks, ck, o = _mk(tfhe, orc, parties, l, beta, n, max(parties, 2) if which != "3-of-4" else 4, 80 + parties)
@@ -165,6 +165,10 @@ def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
     x, y = _words(rng, 4, w), _words(rng, 4, w)[::-1].copy()
     x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
     y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    if which in ("4party", "8party"):
+        # default for the shipped shapes: two waves per rotation, compile-time (parties, l); DIAG instantiation included
+        _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_g2<{parties},{l}>")
+        eng.set_option("mkg_variant", 1)
     _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_general(P={parties},L={l}" + (",acc=global)" if parties > 4 else ")"))
     ck.close()
 

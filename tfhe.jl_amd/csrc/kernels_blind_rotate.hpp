@@ -61,6 +61,39 @@ __device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double wor
     }
 }
 
+// Index of this thread's wave within its workgroup as a SCALAR: everything derived from it (the rotation it works on, its
+// buffers, which half of a split it takes) then lives in scalar registers and branches on it are scalar branches — the
+// compiler cannot see that threadIdx.x >> 6 is wave-uniform and otherwise keeps pointers per lane, masks EXEC around
+// wave-uniform ifs and, in the register-bound kernels, spills those per-lane copies.
+#ifdef TFHE_NO_WAVE_SCALAR       // A/B builds only
+__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
+#else
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#endif
+// A blind rotation's exponents are read one step ahead through the SCALAR cache (s_load_dword: constant address space): the
+// row was written by the prologue kernel of the same batch call, i.e. before this launch, and the value — the same for
+// every lane — then waits in a scalar register instead of a vector register that is live across the whole step.
+__device__ __forceinline__ int32_t load_uniform_i32(const int32_t *p)
+{
+#ifdef TFHE_NO_UNIFORM_LOAD      // A/B builds only
+    return *p;
+#else
+    return *(const __attribute__((address_space(4))) int32_t *)(p);
+#endif
+}
+
+// This thread's lane, recomputed (two instructions) instead of read from the register threadIdx.x arrived in: a kernel that is
+// short of registers then need not keep (or spill) that register for the whole launch.
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// ... and a copy the compiler cannot merge with earlier ones (it counts up from an opaque zero): for use inside a loop whose
+// body should rebuild its per-lane addresses rather than hold them in registers from before the loop.
+__device__ __forceinline__ int lane_id_fresh()
+{
+    unsigned z = 0;
+    asm volatile("" : "+s"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the body needs I as a constant expression)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -333,10 +366,10 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
     }
 
-    int a_next = bara[0] & (2 * kN - 1);
+    int a_next = load_uniform_i32(bara) & (2 * kN - 1);
     for (int i = 0; i < P.n; i++) {
         const int a = a_next;
-        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         wave_priority_step(i, P.prio_steps);
 
         cplx out[K1][8];
@@ -561,6 +594,86 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
     dft8<true>(x);
 }
 
+// The same transforms with the pass-A twiddles read from a table in LDS ([8][64], shared by the workgroup) instead of 32
+// registers per wave: for kernels whose steps are long (many parties: 30 to 81 transforms and 0.3 to 1.2 MB of key per
+// step) the 8 extra 16-byte reads per transform are ~1 % of a step, and the freed registers are what lets three spectrum
+// accumulators, a transform and two key polynomials in flight fit 256 registers at two waves per SIMD.
+// Values [FROM, TO) of a key polynomial (8 per lane, 1 KiB apart) from a UNIFORM base pointer: the base is pinned to scalar
+// registers and the lane enters as a 32-bit offset, so the loads take the "scalar base + vector offset + immediate" form and
+// no 64-bit per-lane address is ever built (those pairs were what the register-bound kernels spilled); the upper four values
+// are beyond the 4 KiB immediate range and use a second scalar base.
+template <int FROM, int TO>
+__device__ __forceinline__ void load_key_values(const cplx *poly, int lane, cplx (&k)[8])
+{
+    // (explicitly global: a pointer that has been through an asm operand is otherwise a generic one, and the loads become
+    //  flat_load — both counters, no counted waits)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(1))) double2 *gptr;
+    gptr lo = (gptr)poly, hi = lo + 256;
+    asm volatile("" : "+s"(lo));
+    asm volatile("" : "+s"(hi));
+#pragma unroll
+    for (int k2 = FROM; k2 < TO; k2++) {
+        const double2 v = k2 < 4 ? lo[(unsigned)(k2 * 64 + lane)] : hi[(unsigned)((k2 - 4) * 64 + lane)];
+        k[k2] = mk(v.x, v.y);
+    }
+#else
+#pragma unroll
+    for (int k2 = FROM; k2 < TO; k2++) k[k2] = poly[k2 * 64 + lane];
+#endif
+}
+
+// (the table pointer passes through an opaque zero offset: the loads would otherwise be hoisted out of the caller's loops —
+//  the table never changes — straight back into the 32 registers this variant exists to free)
+template <typename T>
+__device__ __forceinline__ const T *opaque_table(const T *p)
+{
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return p + z;
+}
+template <typename MID>
+__device__ __forceinline__ void fft_fwd_wave_mid_lt(int lane, cplx (&x)[8], const cplx *tw1f_lds, const cplx *tw2_lds, cplx *xch, MID &&mid)
+{
+    tw1f_lds = opaque_table(tw1f_lds);
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f_lds[q * 64 + lane]);
+    x1_store_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_b(lane, x, xch);
+    dft8<false>(x);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    WAVE_LDS_FENCE();
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    mid();
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+    WAVE_LDS_FENCE();
+    dft8<false>(x);
+}
+__device__ __forceinline__ void fft_inv_wave_lt(int lane, cplx (&x)[8], const cplx *tw1f_lds, const cplx *tw2_lds, cplx *xch)
+{
+    tw1f_lds = opaque_table(tw1f_lds);
+    dft8<true>(x);
+    x2_store(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x2_load(lane, x, xch);
+#pragma unroll
+    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], tw2_lds[q * 8 + (lane & 7)]);
+    dft8<true>(x);
+    WAVE_LDS_FENCE();
+    x1_store_b(lane, x, xch);
+    WAVE_LDS_FENCE();
+    x1_load_a(lane, x, xch);
+    WAVE_LDS_FENCE();
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f_lds[q * 64 + lane]);
+    dft8<true>(x);
+}
+
 template <int L, int PARTY, bool MARGIN>
 __device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
@@ -671,7 +784,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 // polynomials.  Two barriers per step (hand-off written / accumulator updated).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
 // reuses the transposition buffers).  Same words as mk_blind_rotate_kernel.  L must be even.
 template <int L, int PARTY, int WV, bool MARGIN>
-__device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
+__device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                 cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
                                                 int32_t xormask, double &worst)
 {
@@ -683,13 +796,18 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
 #endif
     constexpr int MKPN = TFHE_MK_KPN;
     const int beta = P.g.log2_base;
-    int a_next = bara[PARTY * P.n] & (2 * kN - 1);
+    int a_next = load_uniform_i32(bara + PARTY * P.n) & (2 * kN - 1);
     STAMP_DECL;
 #pragma unroll 1
     for (int j = 0; j < P.n; j++) {
         wave_priority_step(PARTY * P.n + j, P.prio_steps);
         const int a = a_next;
-        a_next = bara[PARTY * P.n + j + 1] & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
+        a_next = load_uniform_i32(bara + PARTY * P.n + j + 1) & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
+        // (the lane is made opaque once per step: per-lane addresses — the 64-bit key pointer, the LDS transposition and
+        //  accumulator offsets — are then rebuilt from scalar bases here instead of living, and being spilled, across the
+        //  whole loop)
+        (void)lane_in;
+        const int lane = lane_id_fresh();
         const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
         cplx out[NP + 1][8];                      // partial sums of the new a_0, a_1, b over this wave's transforms
 #pragma unroll
@@ -729,10 +847,16 @@ __device__ __forceinline__ void mk2_party_steps(int lane, const MkBrArgs &P, con
                     for (int k2 = 0; k2 < MKPN; k2++) kbo[k2] = k_body[k2 * 64];
                 });
                 STAMP(1);
+                // The second key polynomial arrives in two halves: the rest of its first half now, its second half (and the third
+                // polynomial, into kpa's registers) only after the first product has consumed kpa — with all of it requested
+                // at once the step held 270 values live and spilled (60 B / lane of scratch in round 2).
 #pragma unroll
-                for (int k2 = MKPN; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
+                for (int k2 = MKPN; k2 < 4; k2++) kbo[k2] = k_body[k2 * 64];
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kpa[k2], out[PARTY][k2]);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k2 = 4; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
                 if (s == OTHER) {
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_other[k2 * 64];
@@ -795,8 +919,8 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 1, tid_r = tid & 127;
-    const int rot = tid >> 7;                                                    // rotation within the workgroup
+    const int lane = lane_id(), wib = wave_in_block(), wv = wib & 1;
+    const int rot = wib >> 1;                                                    // rotation within the workgroup
     constexpr size_t kRotBytes = (NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx);
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);      // [NP+1][kImg]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + (NP + 1) * kImg * 4);   // [2 waves][kXchElems]
@@ -812,7 +936,7 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     cplx tw1f[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
-    if (tid < 64) tw2_lds[tid] = P.T.tw2[tid];
+    if (wib == 0) tw2_lds[lane] = P.T.tw2[lane];
     // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
     if (wv == 0) { init_zero_poly(lane, acc_lds); init_zero_poly(lane, acc_lds + kImg); }
     else init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
@@ -827,11 +951,12 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
         mk2_party_steps<L, 1, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
     }
     if (!live) return;
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
+    const int lane_e = lane_id_fresh();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, wv == 0 && lane_e == 0);
     // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
     int32_t *ext = P.ext + w * (NP * kN + 1);
-    extract_mask_poly(lane, acc_lds + wv * kImg, ext + wv * kN);                  // wave c extracts mask column c
-    if (tid_r == 0) ext[NP * kN] = acc_lds[NP * kImg + kMir];
+    extract_mask_poly(lane_e, acc_lds + wv * kImg, ext + wv * kN);                // wave c extracts mask column c
+    if (wv == 0 && lane_e == 0) ext[NP * kN] = acc_lds[NP * kImg + kMir];
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
@@ -850,6 +975,7 @@ struct MkGenArgs {
     Gadget g;
     int32_t n, mu, parties, L;
     int32_t *acc;         // ACCG only: [rotations rounded up to the workgroup size][P+1][N] accumulators in global memory
+    int32_t prio_steps;   // mk_blind_rotate_kernel_g2: of the P * n steps of a rotation; see wave_priority_begin
 };
 
 // RW rotations (one wave each) per workgroup, kept in lockstep by one barrier per CMUX step: the 4- and 8-party keys are
@@ -867,7 +993,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
-    const int lane = threadIdx.x & 63, rot = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, rot = wave_in_block();
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
     const size_t rot_bytes = (ACCG ? 0 : (size_t)(NP + 1) * kImg * 4) + (kXchElems + 64) * sizeof(cplx);
     int32_t *acc_lds = ACCG ? P.acc + w_raw * (size_t)(NP + 1) * kImg                // [NP+1][kImg] (the name stays: LDS in the default build)
@@ -963,6 +1089,176 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, lane == 0);
 }
 
+// ---- multi-key blind rotation for the shipped 4- and 8-party sets: compile-time (parties, l), TWO waves per rotation ----
+// mktfhe_parameters_4party / _8party (mk_api.jl:16-34) at 1024 rotations are one wave per SIMD with one wave per rotation,
+// and the any-party kernel above additionally needs a whole SIMD's registers.  Here a rotation is two waves that split the
+// (P + 1) l forward transforms of a step by SOURCE polynomial, so that the new mask a'_s of a non-party source s — fed by
+// its own digits only (mk_internals.jl:377-378) — is finished entirely inside the wave that owns s and nothing of it is
+// exchanged:
+//     wave 0: the first n0 = ceil((P-1)/2) non-party sources, digits [0, d0) of the body;
+//     wave 1: the other n1 non-party sources, the party's own mask, digits [d0, l) of the body
+// (d0 balances the transform counts of the two waves: 12 + 3 vs 13 + 2 at 4 parties, 36 + 5 vs 36 + 4 at 8).  Each wave
+// keeps partial sums of a'_party and b' over its sources; at the end of the step wave 1 hands its a'_party partial to
+// wave 0 and wave 0 its b' partial to wave 1 (each through its own transposition buffer; the inverse transforms then run
+// in the other wave's buffer as in mk_blind_rotate_kernel_w2: two barriers per step).  The accumulator (P + 1 polynomial
+// images) lives in global memory, L2-resident, as in the any-party kernel's ACCG variant: LDS holds the two transposition
+// buffers only (18.4 KB per rotation), so all 1024 rotations are resident at two waves per SIMD; a wave reads a polynomial
+// another wave wrote only across the end-of-step barrier + workgroup-scope fence.  RW rotations per workgroup advance in
+// lockstep and share their key fetches (the 8-party key is 4.7 GB as spectra).
+// Everything that depends on (party, wave, source) is a compile-time constant — one copy of the step per (party, wave), the
+// sources unrolled inside it — exactly as in the 2-party kernel: a first version with run-time source lists and ONE copy of
+// the step needed its pass-A twiddles and the decomposed source in LDS to fit 256 registers and was 15 % SLOWER than the
+// any-party kernel (5.0 vs 4.35 ms per 96 steps x 1024 rotations: +40 % LDS reads per transform at two waves per SIMD).
+template <int NP, int L, int PARTY, int WV, bool MARGIN>
+__device__ __forceinline__ void g2_party_steps(const MkGenArgs &P, const int32_t *bara, int32_t *acc, cplx *xch_own, cplx *xch_oth,
+                                               const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
+{
+    constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
+    constexpr int N0 = NP / 2, N1 = NP - 1 - N0;  // non-party sources of wave 0 / wave 1 (N0 = ceil((NP-1)/2))
+    constexpr int D0raw = ((N1 - N0 + 2) * L + (N1 - N0)) / 2;
+    constexpr int D0 = D0raw < 0 ? 0 : D0raw > L ? L : D0raw;          // body digits [0, D0) -> wave 0, [D0, L) -> wave 1
+    const int beta = P.g.log2_base;
+    int a_next = load_uniform_i32(bara + (size_t)PARTY * P.n) & (2 * kN - 1);
+#pragma unroll 1
+    for (int j = 0; j < P.n; j++) {                                              // mk_internals.jl:476
+        wave_priority_step(PARTY * P.n + j, P.prio_steps);
+        const int a = a_next;
+        a_next = load_uniform_i32(bara + (size_t)PARTY * P.n + j + 1) & (2 * kN - 1);    // the row ends with barb: in range
+        const int lane = lane_id_fresh();      // per-lane addresses are rebuilt every step, not kept (spilled) across the loop
+        const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
+        cplx o_party[8], o_body[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { o_party[q] = mk(0.0, 0.0); o_body[q] = mk(0.0, 0.0); }
+        static_for<0, NP + 1>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            constexpr bool is_body = (s == NP), is_party = (s == PARTY);
+            constexpr int rank = s < PARTY ? s : s - 1;                         // among the non-party masks
+            constexpr bool mine = is_body ? true : is_party ? (WV == 1) : ((rank < N0) == (WV == 0));
+            constexpr int p_begin = is_body ? (WV ? D0 : 0) : 0, p_end = !mine ? 0 : is_body ? (WV ? L : D0) : L;
+            if constexpr (p_begin < p_end) {
+                constexpr bool has_self = !is_body && !is_party;
+                cplx o_self[8];
+                if constexpr (has_self) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o_self[q] = mk(0.0, 0.0);
+                }
+                int32_t temp[16];
+                rotate_poly<16>(lane, a, acc + s * kImg, P.g.offset, xormask, temp);
+#pragma unroll 1
+                for (int p = p_begin; p < p_end; p++) {
+                    const cplx *k_party = key + (size_t)(is_body ? 2 * L * NP + L + p : L * NP + p * NP + s) * kM;   // c1[p] | y[p, s]   -> a'_party
+                    const cplx *k_body = key + (size_t)(is_body ? 2 * L * NP + p : p * NP + s) * kM;                 // c0[p] | x[p, s]   -> b'
+                    const cplx *k_self = key + (size_t)(L * NP + p * NP + PARTY) * kM;                               // y[p, party]       -> a'_s
+                    cplx kpa[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_party[k2 * 64];
+                    cplx x[8];
+                    load_digits2(temp, p + 1, beta, x);
+                    cplx kbo[8];
+                    fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch_own, [&]() {
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; k2++) kbo[k2] = k_body[k2 * 64];
+                    });
+#pragma unroll
+                    for (int k2 = 2; k2 < 8; k2++) kbo[k2] = k_body[k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cfma(x[k2], kpa[k2], o_party[k2]);
+                    if constexpr (has_self) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_self[k2 * 64];
+                    }
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cfma(x[k2], kbo[k2], o_body[k2]);
+                    if constexpr (has_self) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) o_self[k2] = cfma(x[k2], kpa[k2], o_self[k2]);
+                    }
+                }
+                if constexpr (has_self) {      // a'_s complete: only source s feeds it, only this wave read acc[s] in this step
+                    fft_inv_wave(lane, o_self, tw1f, tw2_lds, xch_own);
+                    accumulate_poly<MARGIN>(lane, o_self, acc + s * kImg, &worst);
+                }
+            }
+        });
+        // hand-off: each wave leaves the partial sum the other one finishes in its OWN transposition buffer
+        WAVE_LDS_FENCE();
+        if constexpr (WV == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) xch_own[k2 * 64 + lane] = o_body[k2];
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) xch_own[k2 * 64 + lane] = o_party[k2];
+        }
+        __syncthreads();
+        // the inverse transform runs in the OTHER wave's buffer, the one just read (see mk_blind_rotate_kernel_w2)
+        if constexpr (WV == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cadd(o_party[k2], xch_oth[k2 * 64 + lane]);
+            WAVE_LDS_FENCE();
+            fft_inv_wave(lane, o_party, tw1f, tw2_lds, xch_oth);
+            accumulate_poly<MARGIN>(lane, o_party, acc + PARTY * kImg, &worst);
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cadd(o_body[k2], xch_oth[k2 * 64 + lane]);
+            WAVE_LDS_FENCE();
+            fft_inv_wave(lane, o_body, tw1f, tw2_lds, xch_oth);
+            accumulate_poly<MARGIN>(lane, o_body, acc + NP * kImg, &worst);
+        }
+        // accumulator stores of this step visible to the other wave of the rotation; also ends the use of the LDS hand-off
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int NP, int L, bool MARGIN = false, int RW = 2>
+__global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_g2(MkGenArgs P)
+{
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wib = wave_in_block(), wv = wib & 1, rot = wib >> 1;
+    cplx *xch_all = reinterpret_cast<cplx *>(smem) + (size_t)rot * 2 * kXchElems;          // [2 waves][kXchElems]
+    cplx *tw2_lds = reinterpret_cast<cplx *>(smem) + (size_t)RW * 2 * kXchElems;           // [8][8]
+    cplx *xch_own = xch_all + wv * kXchElems, *xch_oth = xch_all + (1 - wv) * kXchElems;
+    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const bool live = w_raw < (size_t)P.R;                                       // a padding rotation repeats the last one, stores nothing
+    const size_t w = live ? w_raw : (size_t)P.R - 1;
+    int32_t *acc = P.acc + w_raw * (size_t)(NP + 1) * kImg;                      // [NP+1][kImg], global memory
+    const int32_t *bara = P.bara + w * ((size_t)NP * P.n + 1);
+    const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
+
+    cplx tw1f[8];
+    {
+        const int lane0 = lane_id();
+#pragma unroll
+        for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane0];
+        if (wib == 0) tw2_lds[lane0] = P.T.tw2[lane0];
+        // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79 : the polynomials are shared out by parity
+        for (int s = wv; s < NP; s += 2) init_zero_poly(lane0, acc + s * kImg);
+        if (wv == (NP & 1)) init_body_poly(lane0, load_uniform_i32(bara + (size_t)NP * P.n) & (2 * kN - 1), P.mu, acc + NP * kImg);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    wave_priority_begin(P.prio_steps);
+    // party-major double loop (mk_internals.jl:475-476), one instantiation of the steps per (party, wave)
+    if (wv == 0) {
+        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 0, MARGIN>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
+    } else {
+        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 1, MARGIN>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
+    }
+    if (!live) return;
+    const int lane_e = lane_id_fresh();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, wv == 0 && lane_e == 0);
+    // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
+    int32_t *ext = P.ext + w * ((size_t)NP * kN + 1);
+    for (int c = wv; c < NP; c += 2) extract_mask_poly(lane_e, acc + c * kImg, ext + (size_t)c * kN);
+    if (wv == 0 && lane_e == 0) ext[(size_t)NP * kN] = acc[NP * kImg + kMir];
+}
+
 // ---- small and medium batches (up to 1024 rotations): two waves per blind rotation --------------------
 // With fewer rotations than wave slots (single gates, sequential circuits, small batches) one wave per
 // rotation leaves the chip idle and a gate takes n x (4 forward + 2 inverse transforms) of latency.
@@ -988,7 +1284,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [2][kXchElems]: the waves swap them every step
     cplx *tw2_lds = xch_all + 2 * kXchElems;                                     // [8][8]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = tid >> 6;                                                     // wave = owned polynomial
+    const int wv = wave_in_block();                                              // wave = owned polynomial
     int32_t *acc_lds = acc_all + wv * kImg;
     const size_t w = blockIdx.x;
     const int32_t *bara = P.bara + w * (P.n + 1);
@@ -1004,13 +1300,13 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     __syncthreads();
     STAMP_DECL;
 
-    int a_next = bara[0] & (2 * kN - 1);
+    int a_next = load_uniform_i32(bara) & (2 * kN - 1);
     wave_priority_begin(P.prio_steps);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         wave_priority_step(i, P.prio_steps);
         const int a = a_next;
-        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         // key polys of transform (p, c = wv): [i][p][c][co][8][64]
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
         // Transposition buffers: in step i this wave transforms in buffer (wv ^ i) & 1 and leaves its hand-off there; after
@@ -1178,7 +1474,7 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);               // [W][kH2Buf]
     cplx *extra_all = tb_all + W * kH2Buf;                                       // [W][256]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = tid >> 6;                                                     // wave = (p, c, h): owners (p = 0) are waves 0..3, one per SIMD
+    const int wv = wave_in_block();                                              // wave = (p, c, h): owners (p = 0) are waves 0..3, one per SIMD
     const int h = wv & 1, c = (wv >> 1) & 1, p = wv >> 2;
     const bool owner = (p == 0);                                                 // owns half h of output component co = c
     int32_t *acc_lds = acc_all + c * kImg;
@@ -1210,12 +1506,12 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     cplx kown[4], koth[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) { kown[q4] = key_own[q4 * 128]; koth[q4] = key_oth[q4 * 128]; }
-    int a_next = bara[0] & (2 * kN - 1);
+    int a_next = load_uniform_i32(bara) & (2 * kN - 1);
     STAMP_DECL;
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         const int a = a_next;
-        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         cplx x[4];
         int32_t cur[16];                          // this lane's coefficients of polynomial c (an owner adds its half back at the end)
         {
@@ -1467,13 +1763,17 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, tid_r = tid & 127;              // tid_r: thread within its rotation
-    const int rot = tid >> 7;                                                     // rotation within the workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wib = wave_in_block();
+    const int rot = wib >> 1;                                                     // rotation within the workgroup
     constexpr size_t kRotBytes = K1 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx);
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][kImg2]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kImg2 * 4);   // [2 waves][kXchElems]
     cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
-    const bool wave1 = ((tid >> 6) & 1) != 0;                                     // wave-uniform
+    // (which half a wave takes is deliberately NOT derived from the scalar wave index: measured on one device, config 4b,
+    //  44.6 ms this way against 46.5 ms with a scalar `wave1` and 45.0 ms with nothing scalar — the per-wave constants of
+    //  the radix-2 split are then selected per lane instead of by branches)
+    const bool wave1 = ((tid >> 6) & 1) != 0;
     cplx *xch = xch_all + (wave1 ? kXchElems : 0);
     cplx *xch_other = xch_all + (wave1 ? 0 : kXchElems);
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
@@ -1501,13 +1801,13 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     __syncthreads();
     STAMP_DECL;
 
-    int a_next = bara[0] & (2 * kN2 - 1);
+    int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
     wave_priority_begin(P.prio_steps);
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         wave_priority_step(i, P.prio_steps);
         const int a = a_next;
-        a_next = bara[i + 1] & (2 * kN2 - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);   // bara[n] (= barb) exists: harmless read on the last step
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;
         cplx out[K1][8];
 #pragma unroll
@@ -1589,12 +1889,14 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
                 constexpr int R = decltype(rc)::value;
                 const cplx al = alpha[R], be = beta[R];
                 const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
-                const double br = be.x * er + be.y * ei, bi = be.x * ei - be.y * er;    // conj(beta) e_r
+                // conj(beta) e_r   (r = 0 and r = 4 written out: without fast-math the products by 0 and 1 are not folded)
+                const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
+                const double bi = R == 0 ? -be.y : R == 4 ? -be.x : be.x * ei - be.y * er;
                 // (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024        conj(alpha) = (al.x, -al.y)
                 // (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
                 const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
                 const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
-                const double re0 = pr * c0r - pi * c0i, im0 = pr * c0i + pi * c0r;
+                const double re0 = R == 0 ? pr : pr * c0r - pi * c0i, im0 = R == 0 ? pi : pr * c0i + pi * c0r;
                 const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
                 if (MARGIN) {
                     const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
@@ -1618,17 +1920,18 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
         __syncthreads();
         STAMP(9);
     }
-    STAMP_FLUSH(P.diag, threadIdx.x >> 6);
+    STAMP_FLUSH(P.diag, wib);
 
     if (!live) return;
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_r == 0);
+    const int tid_e = ((wib & 1) << 6) + lane_id_fresh();      // thread within its rotation, rebuilt: threadIdx.x need not survive the loop
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_e == 0);
     int32_t *ext = P.ext + w * (kN2 + 1);
-    for (int j = tid_r; j < kN2; j += 128) {
+    for (int j = tid_e; j < kN2; j += 128) {
         const int32_t v = acc_lds[kMir + j];
         if (j == 0) ext[0] = v;
         else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
     }
-    if (tid_r == 0) ext[kN2] = acc_lds[kImg2 + kMir];
+    if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
 }
 
 // key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024

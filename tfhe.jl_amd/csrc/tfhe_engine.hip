@@ -111,6 +111,7 @@ struct tfhe_ctx {
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
     int mkg_rw = 0;                // any-party kernel: rotations per workgroup, in lockstep (0: two; otherwise a cap, at most 4 and what fits in LDS)
+    int mkg_variant = 0;           // 4- / 8-party shipped sets: 0 = two-wave kernel with compile-time (parties, l), 1 = the any-party kernel
     int mkg_acc = -1;              // any-party kernel: accumulators in LDS (0) / in global memory (1) / by party count (-1: global above 4 parties)
     int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
@@ -1405,6 +1406,34 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         }
 #undef LAUNCH_MK
         name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
+    } else if (!c->mk_force_general && c->mkg_variant != 1 && ((NP == 4 && c->P.bs_l == 5) || (NP == 8 && c->P.bs_l == 8))) {
+        // the shipped 4- and 8-party sets (mk_api.jl:16-34): compile-time (parties, l), two waves per rotation at two waves per
+        // SIMD, accumulators in global memory.  LDS: two transposition buffers per rotation and the pass-B twiddle table;
+        // two rotations per workgroup in lockstep (a single rotation gets a padding partner)
+        MkGenArgs ga;
+        ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
+        ga.prio_steps = a.prio_steps;
+        const int rw = 2;
+        const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx);
+        const unsigned nblk = (unsigned)((B + rw - 1) / rw);
+        HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
+        ga.acc = (int32_t *)c->mk_acc.p;
+#define LAUNCH_G2(PP, LL, DG, RWV)                                                                                 \
+        do {                                                                                                       \
+            if (ldsg2 > 64 * 1024)                                                                                 \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_g2<PP, LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg2)); \
+            hipLaunchKernelGGL((mk_blind_rotate_kernel_g2<PP, LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsg2, s, ga); \
+        } while (0)
+#define LAUNCH_G2_PL(PP, LL)                                                                                       \
+        do {                                                                                                       \
+            if (dg) LAUNCH_G2(PP, LL, true, 2);                                                                    \
+            else LAUNCH_G2(PP, LL, false, 2);                                                                      \
+        } while (0)
+        if (NP == 4) LAUNCH_G2_PL(4, 5);
+        else LAUNCH_G2_PL(8, 8);
+#undef LAUNCH_G2_PL
+#undef LAUNCH_G2
+        name_kernel(c, "mk_blind_rotate_kernel_g2<%d,%d>", NP, c->P.bs_l);
     } else {
         MkGenArgs ga;
         ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
@@ -1419,6 +1448,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         const size_t ldsg = (size_t)rw * lds_rot;
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         ga.acc = nullptr;
+        ga.prio_steps = 0;
         if (accg) {
             HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
             ga.acc = (int32_t *)c->mk_acc.p;
@@ -1667,6 +1697,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "mkg_acc")) {
         if (value < -1 || value > 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_acc must be -1 (by party count), 0 (LDS) or 1 (global memory)");
         c->mkg_acc = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "mkg_variant")) {
+        if (value != 0 && value != 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_variant must be 0 (two-wave kernel for the shipped 4- / 8-party sets) or 1 (any-party kernel)");
+        c->mkg_variant = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "mkg_rw")) {
