@@ -267,8 +267,8 @@ def main():
             eng.gates_dev(ops, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), dout.data_ptr(), B, stream)
             if gatherer:
                 gatherer.launch(k, dout)
-        if record:
-            br_ms.append(eng.last_timing_ms(0))   # HIP events on the stream the kernels were launched on
+        if record and args.fanout:
+            br_ms.append(eng.last_timing_ms(0))   # (a multi-device context reports the slowest shard of the call just made)
             ks_ms.append(eng.last_timing_ms(1))
 
     def drain():
@@ -291,6 +291,11 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    if not args.fanout:
+        # HIP events the engine recorded around its kernels on the stream they were launched on, for the timed steps, read
+        # now in one go: no synchronisation between the steps themselves (the engine keeps the events of its last 32 calls)
+        br_ms = eng.timing_history_ms(0, min(args.steps, 32))
+        ks_ms = eng.timing_history_ms(1, min(args.steps, 32))
     rotations_per_step = eng.last_rotation_count()   # of the timed launches (read before any other call on eng)
     kernel_name = eng.last_kernel_name()
     if use_dist:
@@ -301,14 +306,34 @@ def main():
     # --- correctness of what was just timed (not timed itself) ---------------------------------------
     out = host_out if args.fanout else dout.cpu().numpy()
     ok_decrypt = bool(np.array_equal(tfhe.decrypt(sk, out), expect))
-    gather_ok = None
+    # The first multi-GPU run validates itself: every rank reports a position-weighted checksum of the words it computed and
+    # whether they decrypt; rank 0 recomputes the checksum of every shard AS IT ARRIVED through the gather.
+    def checksum(a):
+        a = np.ascontiguousarray(a, np.int32).view(np.uint32).astype(np.uint64).reshape(-1)
+        return int((a * (np.arange(a.size, dtype=np.uint64) % np.uint64(65521) + np.uint64(1))).sum() & np.uint64(0x7FFFFFFFFFFFFFFF))
+    gather_ok = gather_sums_ok = all_ranks_decrypt = None
+    if use_dist:
+        mine = torch.tensor([checksum(out), int(ok_decrypt)], dtype=torch.int64, device="cpu" if share_gpu else dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        all_ranks_decrypt = bool(all(int(t[1]) == 1 for t in every))
     if gatherer and rank == 0:
         g = gatherer.result((step_no - 1) & 1).cpu().numpy()
         s0, e0 = bounds[0]
         gather_ok = bool(g.shape[0] == bounds[-1][1] and np.array_equal(g[s0:e0], out))
+        gather_sums_ok = bool(g.shape[0] == bounds[-1][1] and all(checksum(g[s:e]) == int(every[r][0]) for r, (s, e) in enumerate(bounds)))
+    fanout_ok = None
+    if args.fanout and n_gpus > 1:
+        # one device context recomputes the tail of the LAST shard (computed by the last device of the fan-out): same words
+        from tfhe_jl_amd.sharding import shard_bounds as sb
+        last0 = sb(ops, n_gpus)[-1][0]
+        lo = max(last0, B - 256)
+        one = ck.engine(0)
+        ref = one.gates(ops[lo:], hx[lo:], hy[lo:], hz[lo:] if args.workload == "mixed" else None)
+        fanout_ok = bool(np.array_equal(ref, out[lo:]))
 
     # --- extras on rank 0, outside the timed region ---------------------------------------------------
-    single_ms = pcie_value = clock_mhz = margin = None
+    single_ms = pcie_value = pcie_pageable = clock_mhz = margin = None
     if rank == 0 and not args.fanout:
         if args.workload == "nand":   # "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1)
             one = np.zeros(1, np.uint8)
@@ -325,10 +350,24 @@ def main():
         if not args.no_diagnostics and world == 1:
             # the same step through HOST buffers (tfhe_gates_batch: 2-3 uploads + 1 download over PCIe per step)
             reps = max(2, min(args.steps, 5))
-            eng.gates(ops, hx, hy, hz)
+            hz_ = hz if args.workload == "mixed" else None       # NAND reads no third operand: nothing to upload for it
+            eng.gates(ops, hx, hy, hz_)
             t1 = time.perf_counter()
             for _ in range(reps):
-                eng.gates(ops, hx, hy, hz)
+                eng.gates(ops, hx, hy, hz_)
+            pcie_pageable = B * reps / (time.perf_counter() - t1)
+            # ... and from / into page-locked buffers (tfhe_host_alloc), the result array reused: what a caller that keeps
+            # its ciphertext arrays in such memory gets (the Julia shim's flatten buffers, a server's I/O buffers)
+            px, py, pout = (tfhe.pinned_empty(hx.shape) for _ in range(3))
+            px[:], py[:] = hx, hy
+            pz = None
+            if hz_ is not None:
+                pz = tfhe.pinned_empty(hz.shape); pz[:] = hz
+            eng.gates(ops, px, py, pz, out=pout)
+            assert np.array_equal(pout, out), "host-buffer path differs from the device-buffer path"
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                eng.gates(ops, px, py, pz, out=pout)
             pcie_value = B * reps / (time.perf_counter() - t1)
             # clock the blind-rotate kernel holds under this load + its rounding margin: DIAG instantiation of the
             # same kernel, >= 2 s of back-to-back launches first (MI355X_MICROARCH.md, DVFS give-back item 6)
@@ -380,7 +419,13 @@ def main():
             },
             "outputs_decrypt_correctly": ok_decrypt,
             "gather_matches_local_shard": gather_ok,
+            "gather_matches_every_ranks_checksum": gather_sums_ok,
+            "every_rank_decrypts": all_ranks_decrypt,
+            "fanout_matches_one_device": fanout_ok,
             "value_pcie_inclusive": pcie_value,
+            "value_pcie_inclusive_note": "the same step through tfhe_gates_batch: operands and result in page-locked host memory "
+                                         "(tfhe_host_alloc), H2D + kernels + D2H inside the timed region",
+            "value_pcie_inclusive_pageable": pcie_pageable,
             "roofline": {
                 "bound": "hbm",
                 "bound_note": "judged figure (SURVEY §8d): algorithmic key bytes / launch time against HBM peak; the transformed key "
@@ -394,6 +439,7 @@ def main():
                 "frac_of_measured_copy_rate": achieved / 6.29e12,      # 6.29 TB/s float4 copy (MI355X_MICROARCH.md), quoted beside the 8 TB/s spec
                 "traffic": prof.get("hbm_bytes_per_launch"),
                 "traffic_source": prof.get("source"),
+                "counters_note": prof.get("note"),
                 "bytes_per_unit": br_bytes(params),
                 "units_per_launch": rotations_per_step,
                 "avg_launch_ms": br_avg_s * 1e3,
@@ -426,19 +472,37 @@ def main():
     ck.close()
     if not ok_decrypt:
         sys.exit("bench.py: GPU outputs did not decrypt to the gates' truth values")
-    if gather_ok is False:
-        sys.exit("bench.py: the gathered result does not contain rank 0's shard")
+    if gather_ok is False or gather_sums_ok is False:
+        sys.exit("bench.py: the gathered result differs from what the ranks computed")
+    if all_ranks_decrypt is False:
+        sys.exit("bench.py: some rank's GPU outputs did not decrypt to the gates' truth values")
+    if fanout_ok is False:
+        sys.exit("bench.py: the multi-device context's result differs from a one-device context's")
+
+
+def rocprof_symbol_prefix(kernel_name):
+    """The engine's name for the launched kernel -> the start of its demangled symbol as rocprofv3 prints it:
+    "blind_rotate_kernel_v3<2,8,tw2reg>" is blind_rotate_kernel_v3<2, 8, true, ...>, "...v3<2,16>" is <2, 16, false, ...>."""
+    m = re.fullmatch(r"blind_rotate_kernel_v3<(\d+),(\d+)(,tw2reg)?>", kernel_name)
+    if m:
+        return f"blind_rotate_kernel_v3<{m.group(1)}, {m.group(2)}, {'true' if m.group(3) else 'false'},"
+    return kernel_name.split("(")[0].rstrip(">").replace(",", ", ")
 
 
 def profile_counters(kernel_name, units_per_launch):
-    """PMC-derived figures for the dominant kernel from the newest committed rocprofv3 profile of THIS command
+    """PMC-derived figures for the dominant kernel from a committed rocprofv3 profile of THIS command AND THIS CODE
     (profiles/<tag>/counters.json, written by tools/prof_summary.py from separate --pmc passes): HBM bytes per launch
-    (FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024), VALU instructions, VALU-busy fraction.  They are not
-    measured in this run — the source file is named in the JSON line — and are only reported when that profile was
-    taken at the same number of rotations per launch."""
+    (FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024), VALU instructions, VALU-busy fraction.  PMC counters cannot be
+    read from inside a run, so they are replayed — but only from a profile stamped with the hash of the kernel sources
+    the loaded library was built from (tools/source_hash.py) and taken at the same number of rotations per launch;
+    otherwise the fields are null and `counters_note` says why."""
     import glob
-    key = kernel_name.split("(")[0].rstrip(">")          # "blind_rotate_kernel_v3<2,16" matches "...v3<2, 16, false, false>(BrArgs)"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import kernel_source_sha16
+    want_hash = kernel_source_sha16(ROOT)
+    key = rocprof_symbol_prefix(kernel_name)
     best = {}
+    stale = 0
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "counters.json"))):
         try:
             d = json.load(open(f))
@@ -447,12 +511,18 @@ def profile_counters(kernel_name, units_per_launch):
         meta = d.get("_meta", {})
         if "bench.py" not in meta.get("command", "bench.py"):
             continue
+        if meta.get("kernel_source_sha16") != want_hash:
+            stale += 1
+            continue
         for k, v in d.items():
             if k == "_meta" or v.get("workgroups_per_launch") not in (None, units_per_launch):
                 continue
-            if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k.replace(", ", ",")):
+            if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k):
                 best = dict(v)
-                best["source"] = os.path.relpath(f, ROOT) + (f" ({meta.get('date')})" if meta.get("date") else "")
+                best["source"] = os.path.relpath(f, ROOT) + (f" ({meta.get('date')}, kernel sources {want_hash})" if meta.get("date") else "")
+    if not best:
+        best["note"] = (f"no committed profile of this code (kernel sources {want_hash}; {stale} profile(s) of other versions ignored): "
+                        "run tools/profile.sh and commit its counters.json")
     return best
 
 
@@ -515,6 +585,9 @@ def cpu_baseline(tfhe, params, ck, hx, hy, gpu_out, args):
         "sample": f"first {S} of the {hx.shape[0]} NAND gates of the GPU workload, one gate per OpenMP thread; "
                   f"C restatement of the reference algorithm (not Julia)",
         "single_thread_ms_per_gate": dt1 * 1e3,
+        "ms_per_gate_under_load": threads / (S / dt) * 1e3,
+        "note": (f"DRAM-bound at {threads} threads: every gate streams the 32.8 MB of key spectra and the 49 MB keyswitch key, so "
+                 f"{threads} threads deliver {S / dt * dt1:.1f}x one thread, not {threads}x; value / this is not a compute ratio"),
         "parity_on_sample": bool(np.array_equal(want, gpu_out[:S])),
     }
 

@@ -33,7 +33,7 @@ typedef int32_t (*tfhe_device_count_t)(void);
 typedef int32_t (*tfhe_ctx_create_t)(const tfhe_params *, int32_t, tfhe_ctx **);
 typedef void (*tfhe_ctx_destroy_t)(tfhe_ctx *);
 typedef const char *(*tfhe_last_error_t)(const tfhe_ctx *);
-typedef int32_t (*tfhe_keygen_cloud_key_t)(tfhe_ctx *, const int32_t *, const int32_t *, double, double, uint64_t, int32_t *, int32_t *);
+typedef int32_t (*tfhe_keygen_cloud_key_t)(tfhe_ctx *, const int32_t *, const int32_t *, double, double, const uint32_t *, int32_t *, int32_t *);
 typedef int32_t (*tfhe_gates_batch_t)(tfhe_ctx *, const uint8_t *, const int32_t *, const int32_t *, const int32_t *, int32_t *, int64_t);
 
 int main(int argc, char **argv)
@@ -54,7 +54,11 @@ int main(int argc, char **argv)
     int32_t *lwe_key = malloc(sizeof(int32_t) * n), *tlwe_key = malloc(sizeof(int32_t) * k * N);
     for (int i = 0; i < n; i++) lwe_key[i] = (int32_t)(next_u64() & 1);
     for (int i = 0; i < k * N; i++) tlwe_key[i] = (int32_t)(next_u64() & 1);
-    if (p_tfhe_keygen_cloud_key(ctx, lwe_key, tlwe_key, bs_noise, lwe_noise, next_u64(), NULL, NULL)) {
+    /* six seed words: two for the (public) masks, four — as secret as the key itself — for the noise; a real client draws
+     * them from a cryptographic source, this demo from its test generator */
+    uint32_t seed[6];
+    for (int i = 0; i < 6; i++) seed[i] = (uint32_t)next_u64();
+    if (p_tfhe_keygen_cloud_key(ctx, lwe_key, tlwe_key, bs_noise, lwe_noise, seed, NULL, NULL)) {
         fprintf(stderr, "keygen: %s\n", p_tfhe_last_error(ctx));
         return 6;
     }

@@ -31,13 +31,14 @@
 #ifndef TFHE_MI355X_H
 #define TFHE_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 3
+#define TFHE_MI355X_ABI_VERSION 4
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -140,12 +141,26 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks);
  * (bootstrap.jl:6-15, tgsw.jl:52-88, tlwe.jl:63-73) and KeyswitchKey (keyswitch.jl:14-41, lwe.jl:49-55) — the work
  * CloudKey(rng, secret_key) does on the host (api.jl:111-127).  lwe_key: [n] words 0/1 (SecretKey.key, lwe.jl:11-17);
  * tlwe_key: [k][N] words 0/1 (TLweKey, tlwe.jl:11-21); the noise parameters are bs_noise_stddev / ks_noise_stddev of
- * SchemeParameters (api.jl:4-21).  Randomness is Philox4x32-10 keyed by `seed` (csrc/kernels_keygen.hpp documents the
- * streams; the reference's MersenneTwister stream is not reproduced).  bk_out / ks_out (either may be NULL) receive the
- * canonical Int32 arrays, [n][l][k+1][k+1][N] and [kN][t][base-1][n+1], e.g. to serialise the key.
- * Single-key contexts; a multi-device context generates on its first device and replicates. */
+ * SchemeParameters (api.jl:4-21).  Randomness is Philox4x32-10 (csrc/kernels_keygen.hpp documents the streams; the
+ * reference's MersenneTwister stream is not reproduced) keyed by `seed`, SIX 32-bit words: seed[0..1] key the mask
+ * words, which the cloud key publishes anyway; seed[2..5] are 128 bits that key the noise and are AS SECRET AS THE SECRET
+ * KEY (with them every noise term can be subtracted and the keys solved for): draw them from a cryptographic source, keep
+ * them with the secret key or discard them, never with the cloud key.  The call uploads the secret key bits to the
+ * device for its duration (the context therefore sees the secret key); the scratch copies and the raw noise are zeroed
+ * before their memory is released.  bk_out / ks_out (either may be NULL) receive the canonical Int32 arrays,
+ * [n][l][k+1][k+1][N] and [kN][t][base-1][n+1], e.g. to serialise the key.
+ * Single-key contexts; a multi-device context generates on its first device and replicates through a host copy. */
 int32_t tfhe_keygen_cloud_key(tfhe_ctx *ctx, const int32_t *lwe_key, const int32_t *tlwe_key, double bs_noise_stddev,
-                              double ks_noise_stddev, uint64_t seed, int32_t *bk_out, int32_t *ks_out);
+                              double ks_noise_stddev, const uint32_t *seed /* [6] */, int32_t *bk_out, int32_t *ks_out);
+
+/* ---- host buffers ---------------------------------------------------------------------------- */
+
+/* Page-locked host memory for the operands and results of the host-buffer batch calls below.  Any host pointer works
+ * with them; from pageable memory the runtime stages every copy through its own pinned bounce buffers at roughly half
+ * the PCIe rate, from memory allocated here the copies are single DMA transfers (8.2 MB per operand of a 4096-gate
+ * batch at the 80-bit set).  Not tied to a context; free with tfhe_host_free. */
+int32_t tfhe_host_alloc(size_t bytes, void **out_ptr);
+void tfhe_host_free(void *ptr);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 
@@ -220,6 +235,11 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *ctx, const int32_t *in0, const int32_t
  * were launched on.  which: 0 = blind-rotate kernel(s), 1 = keyswitch kernel(s), 2 = whole batch
  * (prologue .. last kernel, device side).  Blocks until those kernels have finished. */
 int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
+
+/* The same timing of up to the last 32 batch calls on a one-device ctx, oldest first, read in ONE go after the calls: a
+ * caller timing a sequence of asynchronous calls need not synchronise (and so serialise its host work with the device)
+ * after each one.  ms: room for max_calls floats; *n_out = entries written (<= max_calls, <= 32, <= calls made). */
+int32_t tfhe_timing_history_ms(tfhe_ctx *ctx, int32_t which, float *ms, int32_t max_calls, int32_t *n_out);
 
 /* Number of blind rotations the most recent batch call executed (MUX counts 2). */
 int64_t tfhe_last_rotation_count(const tfhe_ctx *ctx);

@@ -152,18 +152,19 @@ function GpuCloudKey(ck::CloudKey; device::Integer=0, devices=nothing, wires::In
 end
 
 # The cloud key generated ON THE GPU (tfhe_keygen_cloud_key) instead of by CloudKey(rng, secret_key) on the host
-# (api.jl:111-127): the TLWE key bits and a 64-bit seed come from `rng`, the bootstrap and keyswitch keys never exist
-# on the host.  The key material follows the library's Philox streams, not MersenneTwister's.  The seed is as secret
-# as the secret key (it regenerates the noise of every key row): it is not stored anywhere.
+# (api.jl:111-127): the TLWE key bits and a seed of six 32-bit words come from `rng` (for real keys: a cryptographic
+# generator such as RandomDevice()), the bootstrap and keyswitch keys never exist on the host.  The key material follows
+# the library's Philox streams, not MersenneTwister's.  Four of the seed words key the noise and are as secret as the
+# secret key (they regenerate the noise of every key row): the seed is not stored anywhere.
 function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing, wires::Integer=65536)
     p = secret_key.params
     gck = GpuCloudKey(p, devices === nothing ? [device] : devices, wires)
     try
         lwe_bits = Int32.(secret_key.key.key)                                        # lwe.jl:11-17
         tlwe_bits = Int32.(rand(rng, Bool, p.tlwe_polynomial_degree, p.tlwe_mask_size))   # [N, k] = C-order [k][N]; tlwe.jl:15-20
-        seed = rand(rng, UInt64)
-        GC.@preserve lwe_bits tlwe_bits check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
-            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, UInt64, Ptr{Int32}, Ptr{Int32}),
+        seed = rand(rng, UInt32, 6)          # words 1-2 key the public masks, words 3-6 (128 bits) the noise: secret, discarded here
+        GC.@preserve lwe_bits tlwe_bits seed check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
+            (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
             gck.ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
     catch
         destroy!(gck)

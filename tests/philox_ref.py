@@ -19,18 +19,21 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def uniform_words(stream, index, seed):
-    """Word `index` (uint64 array) of uniform stream `stream`: output (index & 3) of block (index >> 2)."""
+    """Word `index` (uint64 array) of uniform (mask) stream `stream`: output (index & 3) of block (index >> 2), keyed by
+    seed[0..1] (seed: six 32-bit words, kernels_keygen.hpp)."""
     index = np.asarray(index, np.uint64)
     blk = index >> np.uint64(2)
-    out = philox4x32_10(blk & MASK, blk >> np.uint64(32), np.uint64(stream), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
+    out = philox4x32_10(blk & MASK, blk >> np.uint64(32), np.uint64(stream), np.uint64(0), int(seed[0]), int(seed[1]))
     sel = (index & np.uint64(3)).astype(np.int64)
     return np.choose(sel, out).astype(np.uint32)
 
 
 def gaussians(stream, index, seed):
-    """Standard normal `index` of Gaussian stream `stream`: Box-Muller on outputs 0, 1 of block `index`."""
+    """Standard normal `index` of Gaussian (noise) stream `stream`: Box-Muller on outputs 0, 1 of block `index`, keyed by the
+    secret half of the seed: Philox key seed[2..3], counter words 2, 3 = stream ^ seed[4], seed[5]."""
     index = np.asarray(index, np.uint64)
-    x, y, _, _ = philox4x32_10(index & MASK, index >> np.uint64(32), np.uint64(stream), np.uint64(0), seed & 0xFFFFFFFF, seed >> 32)
+    x, y, _, _ = philox4x32_10(index & MASK, index >> np.uint64(32), np.uint64(stream ^ int(seed[4])), np.uint64(int(seed[5])),
+                               int(seed[2]), int(seed[3]))
     u1 = (x.astype(np.float64) + 0.5) / 4294967296.0
     u2 = (y.astype(np.float64) + 0.5) / 4294967296.0
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925 * u2)

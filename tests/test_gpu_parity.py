@@ -308,3 +308,40 @@ def test_nonstandard_keyswitch_shape_uses_fallback(tfhe, orc):
         ops = np.full(5, tfhe.OPCODES[name], np.uint8)
         assert np.array_equal(eng.gates(ops, x, y, z), K.oracle.gates(ops, x, y, z, nthreads=5))
     K.ck.close()
+
+
+def test_two_stream_host_batches_equal_one_stream(tfhe, keys80, eng80):
+    """tfhe_gates_batch cuts large host-buffer batches in two rotation-balanced halves that run on two streams (the second
+    half's upload and the first half's download overlap the other half's kernels).  Same words as the one-stream path, for
+    a mixed stream with MUX (two rotations), NOT / CONSTANT / COPY (none), from pageable and from page-locked buffers, into
+    a caller-supplied result array; the second stream's context follows a key reload."""
+    K = keys80
+    rng = np.random.default_rng(2024)
+    B = 3000
+    names = ["NAND", "AND", "OR", "XOR", "MUX", "NOT", "CONST1", "COPY", "XNOR"]
+    ops = np.array([tfhe.OPCODES[n] for n in names], np.uint8)[rng.integers(0, len(names), B)]
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
+    eng80.set_option("pipeline_min", -1)
+    want = eng80.gates(ops, *ins)
+    rot = eng80.last_rotation_count()
+    try:
+        eng80.set_option("pipeline_min", 2)
+        got = eng80.gates(ops, *ins)
+        assert np.array_equal(got, want) and eng80.last_rotation_count() == rot
+        pin = [tfhe.pinned_empty(a.shape) for a in ins]
+        for p, a in zip(pin, ins):
+            p[:] = a
+        pout = tfhe.pinned_empty(want.shape)
+        assert eng80.gates(ops, *pin, out=pout) is pout and np.array_equal(pout, want)
+        # an operand array nobody reads may be absent; one that is read may not
+        nand = np.zeros(64, np.uint8)
+        assert np.array_equal(eng80.gates(nand, ins[0][:64], ins[1][:64]), eng80.gates(nand, ins[0][:64], ins[1][:64], ins[2][:64]))
+        with pytest.raises(tfhe.EngineError):
+            eng80.gates(ops[:64], ins[0][:64], ins[1][:64])          # the stream has MUXes: in2 is required
+        # reload the keys: the second stream must use the new buffers
+        eng80.load_bootstrap_key(K.ck.bootstrap_key)
+        eng80.load_keyswitch_key(K.ck.keyswitch_key)
+        assert np.array_equal(eng80.gates(ops, *ins), want)
+    finally:
+        eng80.set_option("pipeline_min", 4096)

@@ -20,11 +20,20 @@ def test_philox4x32_10_known_answers():
 
 def test_stream_helpers_shapes_and_moments():
     idx = np.arange(200000, dtype=np.uint64)
-    w = ph.uniform_words(1, idx, 0x1234567890ABCDEF)
+    seed = np.array([0x90ABCDEF, 0x12345678, 7, 8, 9, 10], np.uint32)
+    w = ph.uniform_words(1, idx, seed)
     assert w.dtype == np.uint32 and abs(w.astype(np.float64).mean() / 2**32 - 0.5) < 0.01
-    assert np.array_equal(w[:8], ph.uniform_words(1, idx[:8], 0x1234567890ABCDEF))
-    g = ph.gaussians(2, idx, 7)
+    assert np.array_equal(w[:8], ph.uniform_words(1, idx[:8], seed))
+    g = ph.gaussians(2, idx, seed)
     assert abs(g.mean()) < 0.01 and abs(g.std() - 1.0) < 0.01 and np.abs(g).max() < 6.8
+    # the two halves of the seed are independent: the mask words depend on words 0-1 only, the noise on words 2-5 only
+    other_noise = seed.copy(); other_noise[2:] += 1
+    other_mask = seed.copy(); other_mask[:2] += 1
+    assert np.array_equal(ph.uniform_words(1, idx[:64], other_noise), w[:64])
+    assert np.array_equal(ph.gaussians(2, idx[:64], other_mask), g[:64])
+    for i in range(2, 6):
+        one = seed.copy(); one[i] ^= 1
+        assert not np.array_equal(ph.gaussians(2, idx[:64], one), g[:64]), f"noise does not depend on seed word {i}"
 
 
 def _predict(tfhe, p, lwe_key, tlwe_key, seed):
@@ -75,7 +84,7 @@ def test_device_key_equals_prediction(tfhe, n, N, k, l, beta):
     rng = np.random.default_rng(1000 + n)
     lwe_key = rng.integers(0, 2, n).astype(np.int32)
     tlwe_key = rng.integers(0, 2, (k, N)).astype(np.int32)
-    seed = 0xC0FFEE1234567 + n
+    seed = np.array([0x01234567 + n, 0xC0FFEE, 0xDEADBEEF, 0x0BADF00D + n, 0x5EED5EED, 0x13572468], np.uint32)
     from tfhe_jl_amd import _lib
     eng = _lib.Engine(p, 0)
     bk, ks = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, seed)
@@ -91,8 +100,15 @@ def test_device_key_equals_prediction(tfhe, n, N, k, l, beta):
     # same seed -> same key; another seed -> another key
     bk2, ks2 = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, seed)
     assert np.array_equal(bk, bk2) and np.array_equal(ks, ks2)
-    bk3, _ = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, seed + 1)
-    assert not np.array_equal(bk, bk3)
+    # another noise key: the published mask words stay, every body changes; another mask key: the masks change
+    s2 = seed.copy(); s2[5] += 1
+    bk3, _ = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, s2)
+    assert np.array_equal(bk3[:, :, :, :k, 1:], bk[:, :, :, :k, 1:]) and not np.array_equal(bk3[:, :, :, k, :], bk[:, :, :, k, :])
+    s3 = seed.copy(); s3[0] += 1
+    bk4, _ = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, s3)
+    assert not np.array_equal(bk4[:, :, :, :k, 1:], bk[:, :, :, :k, 1:])
+    with pytest.raises(ValueError):
+        eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, seed[:2])
     eng.close()
 
 
@@ -132,7 +148,7 @@ def test_device_key_noise_statistics(tfhe):
     lwe_key = rng.integers(0, 2, n).astype(np.int32)
     tlwe_key = rng.integers(0, 2, (1, N)).astype(np.int32)
     eng = _lib.Engine(p, 0)
-    bk, ks = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, 99)
+    bk, ks = eng.keygen_cloud_key(lwe_key, tlwe_key, p.bs_noise_stddev, p.ks_noise_stddev, np.arange(99, 105, dtype=np.uint32))
     eng.close()
     # bootstrap key: body - a * s - message
     a, b = bk[:, :, :, 0, :].astype(np.int64), bk[:, :, :, 1, :].astype(np.int64)
@@ -167,7 +183,7 @@ def test_device_keygen_on_a_multi_device_context(tfhe):
     ck1 = tfhe.CloudKey(rng, sk, keygen="device", device=0)
     rng.bit_generator.state = st
     ck2 = tfhe.CloudKey(rng, sk, keygen="device", device=[0, 0])
-    assert ck1.keygen_seed == ck2.keygen_seed
+    assert not hasattr(ck1, "keygen_seed") and sk.cloud_keygen_seed is not None      # the seed stays on the secret side
     assert np.array_equal(ck1.bootstrap_key, ck2.bootstrap_key) and np.array_equal(ck1.keyswitch_key, ck2.keyswitch_key)
     bits = rng.integers(0, 2, (2, 40)).astype(bool)
     x, y = tfhe.encrypt(rng, sk, bits[0]).data, tfhe.encrypt(rng, sk, bits[1]).data

@@ -13,7 +13,7 @@ from .gates import (gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not,
 from .mk_keys import SharedKey, CloudKeyPart, MKCloudKey, MKLweSample, mk_encrypt, mk_decrypt, mk_gate_nand
 from .circuit import Circuit
 from .serialize import save_cloud_key, load_cloud_key
-from ._lib import Engine, EngineError, OPCODES, LIB_PATH
+from ._lib import Engine, EngineError, OPCODES, LIB_PATH, pinned_empty
 
 __all__ = [
     "make_key_pair", "LweSample", "LweSampleArray", "SecretKey", "CloudKey", "encrypt", "decrypt",
@@ -22,5 +22,5 @@ __all__ = [
     "gate_andny", "gate_andyn", "gate_orny", "gate_oryn", "gate_mux", "gates_batch",
     "mktfhe_parameters_2party", "mktfhe_parameters_4party", "mktfhe_parameters_8party",
     "SharedKey", "CloudKeyPart", "MKCloudKey", "MKLweSample", "mk_encrypt", "mk_decrypt", "mk_gate_nand",
-    "Circuit", "save_cloud_key", "load_cloud_key", "Engine", "EngineError", "OPCODES", "LIB_PATH",
+    "Circuit", "save_cloud_key", "load_cloud_key", "Engine", "EngineError", "OPCODES", "LIB_PATH", "pinned_empty",
 ]

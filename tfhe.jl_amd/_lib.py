@@ -20,9 +20,10 @@ ABI_SYMBOLS = [
     "tfhe_last_rounding_margin", "tfhe_wires_alloc", "tfhe_wires_upload", "tfhe_wires_download", "tfhe_gates_level",
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
-    "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key",
+    "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key", "tfhe_host_alloc", "tfhe_host_free",
+    "tfhe_timing_history_ms",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -31,6 +32,24 @@ OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=
 class TfheParams(C.Structure):
     _fields_ = [(f, C.c_int32) for f in
                 ("n", "N", "k", "bs_l", "bs_log2_base", "ks_t", "ks_log2_base", "parties")]
+
+
+def pinned_empty(shape, dtype=np.int32):
+    """A numpy array in page-locked host memory (tfhe_host_alloc): operands / results of the host-buffer batch calls held
+    in such arrays cross PCIe as single DMA transfers instead of being staged through the runtime's bounce buffers.  The
+    block is returned (tfhe_host_free) when the last view of the array is gone."""
+    import weakref
+    lib = load()
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    p = C.c_void_p()
+    rc = lib.tfhe_host_alloc(nbytes, C.byref(p))
+    if rc:
+        raise MemoryError(f"tfhe_host_alloc({nbytes}) failed: {lib.tfhe_last_error(None).decode()}")
+    buf = (C.c_char * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib.tfhe_host_free, p.value)          # numpy holds `buf` for as long as any view lives
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 class EngineError(RuntimeError):
@@ -64,7 +83,11 @@ def load():
     lib.tfhe_load_bootstrap_key_i32.argtypes = [vp, vp]
     lib.tfhe_load_bootstrap_key_c128.argtypes = [vp, vp]
     lib.tfhe_load_keyswitch_key.argtypes = [vp, vp]
-    lib.tfhe_keygen_cloud_key.argtypes = [vp, vp, vp, C.c_double, C.c_double, C.c_uint64, vp, vp]
+    lib.tfhe_keygen_cloud_key.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
+    if hasattr(lib, "tfhe_host_alloc"):
+        lib.tfhe_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+        lib.tfhe_host_free.argtypes = [vp]
+        lib.tfhe_host_free.restype = None
     lib.tfhe_gates_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.tfhe_gates_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
     lib.tfhe_bootstrap_batch.argtypes = [vp, i32, vp, vp, i64, i32]
@@ -75,6 +98,8 @@ def load():
     lib.tfhe_mk_expand_load_bootstrap_key.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tfhe_mk_gate_nand_batch.argtypes = [vp, vp, vp, vp, i64]
     lib.tfhe_last_timing_ms.argtypes = [vp, i32, C.POINTER(C.c_float)]
+    if hasattr(lib, "tfhe_timing_history_ms"):
+        lib.tfhe_timing_history_ms.argtypes = [vp, i32, C.POINTER(C.c_float), i32, C.POINTER(i32)]
     lib.tfhe_last_rotation_count.argtypes = [vp]
     lib.tfhe_last_rotation_count.restype = i64
     lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
@@ -91,7 +116,7 @@ def load():
     lib.tfhe_last_kernel_name.argtypes = [vp]
     lib.tfhe_last_kernel_name.restype = C.c_char_p
     lib.tfhe_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
-    if lib.tfhe_abi_version() != ABI_VERSION:
+    if lib.tfhe_abi_version() != ABI_VERSION and not os.environ.get("TFHE_MI355X_ALLOW_ABI_MISMATCH"):     # (the override is for A/B runs against an older build)
         raise ImportError(f"{LIB_PATH} has ABI version {lib.tfhe_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
@@ -180,9 +205,13 @@ class Engine:
         self._check(self._lib.tfhe_load_keyswitch_key(self._h, _ptr(ks)))
 
     def keygen_cloud_key(self, lwe_key, tlwe_key, bs_noise_stddev, ks_noise_stddev, seed, want_arrays=True):
-        """Generates bootstrap + keyswitch key on the device and loads them (tfhe_keygen_cloud_key).  Returns the
-        canonical Int32 arrays (bk [n][l][k+1][k+1][N], ks [kN][t][base-1][n+1]) unless want_arrays is False."""
+        """Generates bootstrap + keyswitch key on the device and loads them (tfhe_keygen_cloud_key).  `seed`: six 32-bit
+        words; words 0-1 key the (public) mask streams, words 2-5 are the 128-bit noise key and AS SECRET AS THE SECRET KEY.
+        Returns the canonical Int32 arrays (bk [n][l][k+1][k+1][N], ks [kN][t][base-1][n+1]) unless want_arrays is False."""
         lwe_key, tlwe_key = _i32c(lwe_key), _i32c(tlwe_key)
+        seed = np.ascontiguousarray(seed, dtype=np.uint32).reshape(-1)
+        if seed.size != 6:
+            raise ValueError("keygen_cloud_key: seed must be six 32-bit words (2 for the masks, 4 secret ones for the noise)")
         p = self.params
         if lwe_key.size != self.n or tlwe_key.size != self.k * self.N:
             raise ValueError(f"secret keys have {lwe_key.size} / {tlwe_key.size} words, expected {self.n} / {self.k * self.N}")
@@ -191,18 +220,23 @@ class Engine:
             bk = np.empty((self.n, p.bs_decomp_length, self.k + 1, self.k + 1, self.N), np.int32)
             ks = np.empty((self.k * self.N, p.ks_decomp_length, (1 << p.ks_log2_base) - 1, self.n + 1), np.int32)
         self._check(self._lib.tfhe_keygen_cloud_key(self._h, _ptr(lwe_key), _ptr(tlwe_key), float(bs_noise_stddev),
-                                                    float(ks_noise_stddev), int(seed) & (2**64 - 1), _ptr(bk), _ptr(ks)))
+                                                    float(ks_noise_stddev), _ptr(seed), _ptr(bk), _ptr(ks)))
         return bk, ks
 
     # ---- hot path, host buffers ----
-    def gates(self, opcodes, in0, in1=None, in2=None):
+    def gates(self, opcodes, in0, in1=None, in2=None, out=None):
+        """`out`: an int32 [B][n+1] array to receive the result (e.g. one from pinned_empty, reused across calls);
+        a fresh array otherwise."""
         ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
         B = ops.size
         in0, in1, in2 = _i32c(in0), _i32c(in1), _i32c(in2)
         for a in (in0, in1, in2):
             if a is not None and a.shape != (B, self.n + 1):
                 raise ValueError(f"operand shape {a.shape}, expected {(B, self.n + 1)}")
-        out = np.empty((B, self.n + 1), np.int32)
+        if out is None:
+            out = np.empty((B, self.n + 1), np.int32)
+        elif out.dtype != np.int32 or out.shape != (B, self.n + 1) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous int32 array of shape {(B, self.n + 1)}")
         self._check(self._lib.tfhe_gates_batch(self._h, _ptr(ops), _ptr(in0), _ptr(in1), _ptr(in2), _ptr(out), B))
         return out
 
@@ -322,6 +356,14 @@ class Engine:
         ms = C.c_float(0)
         self._check(self._lib.tfhe_last_timing_ms(self._h, int(which), C.byref(ms)))
         return float(ms.value)
+
+    def timing_history_ms(self, which, max_calls=32):
+        """Kernel-side durations (HIP events) of up to the last 32 batch calls, oldest first, read after the calls in one go
+        (tfhe_timing_history_ms): no synchronisation between the calls themselves."""
+        buf = (C.c_float * int(max_calls))()
+        n = C.c_int32(0)
+        self._check(self._lib.tfhe_timing_history_ms(self._h, int(which), buf, int(max_calls), C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
 
     def last_rotation_count(self):
         return int(self._lib.tfhe_last_rotation_count(self._h))

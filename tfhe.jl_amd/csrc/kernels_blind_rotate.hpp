@@ -1615,6 +1615,8 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 }
 
 // ---- blind rotation for tlwe_mask_size k = 2 (api.jl:30,55 keyword) ---------------------------------
+// (This kernel keeps the accumulator polynomials WITHOUT mirror blocks and rotates with per-lane signs, rotate_sub2: the three
+// mirrors would take its LDS from 22.5 to 23.3 KB per wave, i.e. from seven to six waves per CU — measured 29.0 vs 28.4 ms per 4096 rotations.)
 // Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
 // 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
 template <int L, bool MARGIN = false>
@@ -1625,8 +1627,8 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][kImg]
-    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
+    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
     cplx *tw2_lds = xch + kXchElems;
     const int lane = threadIdx.x;
     const size_t w = blockIdx.x;
@@ -1638,15 +1640,22 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     tw2_lds[lane] = P.T.tw2[lane];
-    init_zero_poly(lane, acc_lds);
-    init_zero_poly(lane, acc_lds + kImg);
-    init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
+    {
+        const int barb = bara[P.n] & (2 * kN - 1);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
+            acc_lds[lane + 64 * m] = 0;
+            acc_lds[kN + lane + 64 * m] = 0;
+            acc_lds[2 * kN + lane + 64 * m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+    }
     WAVE_LDS_FENCE();
 
     // (no wave_priority_* here: 22 KB of LDS per wave put 7 waves on a CU, so one SIMD has a single wave; measured 3 % slower with it)
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
-        const int a = bara[i] & (2 * kN - 1);
+        const int a = load_uniform_i32(bara + i) & (2 * kN - 1);      // through the scalar cache: no vector register held for it
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + lane;
         cplx out[K1][8];
 #pragma unroll
@@ -1656,7 +1665,14 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll 1
         for (int c = 0; c < K1; c++) {
             int32_t temp[16];
-            rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
+            {
+                int32_t cur[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) cur[m] = acc_lds[c * kN + lane + 64 * m];
+                int a_here = a;
+                asm volatile("" : "+v"(a_here));
+                rotate_sub2(lane, a_here, acc_lds + c * kN, cur, P.g.offset, xormask, temp);
+            }
 #pragma unroll 1
             for (int p = 0; p < L; p++) {
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * kM;
@@ -1679,7 +1695,11 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll
         for (int d = 0; d < K1; d++) {
             fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
-            accumulate_poly<MARGIN>(lane, out[d], acc_lds + d * kImg, &worst);
+            int32_t accr[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) accr[m] = acc_lds[d * kN + lane + 64 * m];
+            untwist_add2<MARGIN>(out[d], accr, &worst);
+            for (int m = 0; m < 16; m++) acc_lds[d * kN + lane + 64 * m] = accr[m];
         }
         WAVE_LDS_FENCE();
     }
@@ -1687,8 +1707,15 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
     int32_t *ext = P.ext + w * (2 * kN + 1);
 #pragma unroll
-    for (int c = 0; c < 2; c++) extract_mask_poly(lane, acc_lds + c * kImg, ext + c * kN);
-    if (lane == 0) ext[2 * kN] = acc_lds[2 * kImg + kMir];
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int jj = lane + 64 * m;
+            const int32_t v = acc_lds[c * kN + jj];
+            if (jj == 0) ext[c * kN] = v;
+            else ext[c * kN + kN - jj] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
 }
 
 // ---- N = 2048: two waves per blind rotation ----------------------------------------------------------

@@ -3,9 +3,15 @@
 // canonical Int32 layouts of include/tfhe_mi355x.h.  One-off work (the reference does it on the host in make_key_pair,
 // api.jl:139-146); here it saves the 82-620 MB host-to-device copy and the host's FFT products for large sets.
 //
-// Randomness: Philox4x32-10 (Salmon et al., SC'11), counter-based, keyed by the caller's 64-bit seed, so every word of
-// the key is a pure function of (seed, position) and the test suite restates the stream in numpy (tests/philox_ref.py).
-// The reference's MersenneTwister stream is not reproduced (keys are data that crosses the boundary).
+// Randomness: Philox4x32-10 (Salmon et al., SC'11), counter-based, so every word of the key is a pure function of
+// (seed, position) and the test suite restates the streams in numpy (tests/philox_ref.py).  The reference's
+// MersenneTwister stream is not reproduced (keys are data that crosses the boundary).  The caller's seed is SIX 32-bit
+// words with two roles that must not share key material:
+//   seed[0..1]  key of the MASK streams 1 and 3: their output is published as the `a` words of the cloud key anyway;
+//   seed[2..5]  128 bits that are AS SECRET AS THE SECRET KEY: they key the NOISE streams 2 and 4 (Philox key =
+//               seed[2..3], counter words 2 and 3 = stream ^ seed[4], seed[5]).  Whoever knows them can subtract every
+//               noise term and solve b - e = <a, s> for the secret keys; and because they are independent of the mask
+//               key, the public mask words give no handle for guessing them.
 //   stream 1: bootstrap-key mask words      index = ((sample * k) + c) * N + coefficient
 //   stream 2: bootstrap-key noise           index = sample * N + coefficient
 //   stream 3: keyswitch-key mask words      index = sample * n + m
@@ -33,18 +39,20 @@ __host__ __device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     return U4{c0, c1, c2, c3};
 }
 
-__device__ inline uint32_t uniform_word(uint32_t stream, uint64_t index, uint32_t k0, uint32_t k1)
+struct Seed { uint32_t w[6]; };      // [0..1] mask key (public), [2..5] noise key (secret)
+
+__device__ inline uint32_t uniform_word(uint32_t stream, uint64_t index, const Seed &sd)
 {
     const uint64_t blk = index >> 2;
-    const U4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), stream, 0u, k0, k1);
+    const U4 r = philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), stream, 0u, sd.w[0], sd.w[1]);
     const uint32_t sel = (uint32_t)index & 3u;
     return sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
 }
 
 // standard normal: sqrt(-2 ln u1) cos(2 pi u2), u = (word + 0.5) / 2^32
-__device__ inline double gaussian(uint32_t stream, uint64_t index, uint32_t k0, uint32_t k1)
+__device__ inline double gaussian(uint32_t stream, uint64_t index, const Seed &sd)
 {
-    const U4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream, 0u, k0, k1);
+    const U4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream ^ sd.w[4], sd.w[5], sd.w[2], sd.w[3]);
     const double u1 = ((double)r.x + 0.5) * (1.0 / 4294967296.0), u2 = ((double)r.y + 0.5) * (1.0 / 4294967296.0);
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
 }
@@ -64,7 +72,7 @@ struct Args {
     double *ks_mean;           // [1] scratch
     int32_t n, N, k, l, beta, t, ks_log2_base;
     double bs_alpha, ks_alpha;
-    uint32_t k0, k1;           // seed
+    Seed seed;
 };
 
 // One workgroup per TLWE sample (i, p, j): k uniform mask polynomials, body = sum_c a_c * s_c + e (tlwe.jl:63-73), plus
@@ -88,14 +96,14 @@ __global__ __launch_bounds__(256) void bk_kernel(Args A)
         s_bits[w] = bits;
     }
     for (int e = tid; e < k * N; e += 256) {
-        const uint32_t v = uniform_word(1u, r * (uint64_t)k * N + e, A.k0, A.k1);
+        const uint32_t v = uniform_word(1u, r * (uint64_t)k * N + e, A.seed);
         a_lds[e] = v;
         out[e] = (int32_t)v;
     }
     __syncthreads();
     const uint32_t msg = (uint32_t)(A.lwe_key[i] & 1) << (32 - (p + 1) * A.beta);
     for (int co = tid; co < N; co += 256) {
-        uint32_t acc = dtot32(gaussian(2u, r * (uint64_t)N + co, A.k0, A.k1) * A.bs_alpha);
+        uint32_t acc = dtot32(gaussian(2u, r * (uint64_t)N + co, A.seed) * A.bs_alpha);
         for (int c = 0; c < k; c++) {
             const uint32_t *a = a_lds + c * N;
             for (int w0 = 0; w0 < N / 32; w0++) {
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void bk_kernel(Args A)
 __global__ __launch_bounds__(256) void ks_noise_kernel(Args A, size_t Q)
 {
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (q < Q) A.ks_noise[q] = gaussian(4u, q, A.k0, A.k1) * A.ks_alpha;
+    if (q < Q) A.ks_noise[q] = gaussian(4u, q, A.seed) * A.ks_alpha;
 }
 
 __global__ __launch_bounds__(256) void ks_mean_kernel(Args A, size_t Q)     // one workgroup, fixed summation order
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256) void ks_kernel(Args A, size_t Q)
     int32_t *out = A.ks + q * (size_t)(A.n + 1);
     uint32_t dot = 0;
     for (int m = lane; m < A.n; m += 64) {
-        const uint32_t v = uniform_word(3u, q * (uint64_t)A.n + m, A.k0, A.k1);
+        const uint32_t v = uniform_word(3u, q * (uint64_t)A.n + m, A.seed);
         out[m] = (int32_t)v;
         if (A.lwe_key[m] & 1) dot += v;
     }

@@ -66,7 +66,12 @@ struct tfhe_ctx {
     std::vector<uint8_t> kid_ran;        // which kids took part in the last batch call (timing / diagnostics)
 
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // batch start, BR start/end(=KS start), KS end
+    // Timing events of the last kTimingSlots batch calls (batch start, BR start / end (= KS start), KS end): a caller that
+    // times a sequence of calls reads them all afterwards (tfhe_timing_history_ms) instead of synchronising after each
+    static constexpr int kTimingSlots = 32;
+    hipEvent_t evring[kTimingSlots][4] = {};
+    hipEvent_t *ev = evring[0];          // the current call's set
+    int64_t timed_calls = 0;             // batch calls that recorded a set so far
     hipEvent_t done_ev = nullptr;        // recorded at the end of every batch call: the workspaces are shared, so the next
     bool done_pending = false;           // call makes ITS stream wait for this event (no foreign stream handle is kept)
     bool timing_valid = false;
@@ -116,6 +121,12 @@ struct tfhe_ctx {
     int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
+    // Host-buffer batches of at least `pipeline_min` gates are cut in two rotation-balanced halves that run on two streams of
+    // this device, so that the second half's upload and the first half's download cross PCIe while the other half computes.
+    // The second stream, its workspaces and its events belong to a twin context that BORROWS this context's keys.
+    tfhe_ctx *twin = nullptr;
+    bool borrows_keys = false;
+    int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
 
@@ -256,14 +267,16 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
     };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    for (auto &ev : c->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (auto &set : c->evring)
+        for (auto &ev : set)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->map_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     std::vector<cplx> h;
     build_tables(h);
     if ((e = hipMalloc((void **)&c->d_tables, h.size() * sizeof(cplx))) != hipSuccess) return bail(e, "hipMalloc(tables)");
-    if ((e = hipMemcpy(c->d_tables, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = hipMemcpyAsync(c->d_tables, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(tables)");
     c->T = tables_from(c->d_tables);
     *out_ctx = c;
@@ -302,9 +315,11 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
         delete c;
         return;
     }
+    if (c->twin) { tfhe_ctx_destroy(c->twin); c->twin = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->borrows_keys) c->d_bk = nullptr, c->d_ks = nullptr, c->d_ksp = nullptr, c->d_ks4 = nullptr;      // the owner frees them
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_ks) (void)hipFree(c->d_ks);
     if (c->d_ksp) (void)hipFree(c->d_ksp);
@@ -316,12 +331,25 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release(); c->mk_acc.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
-    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &set : c->evring)
+        for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
     if (c->map_ev) (void)hipEventDestroy(c->map_ev);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+int32_t tfhe_host_alloc(size_t bytes, void **out_ptr)
+{
+    if (!out_ptr) return TFHE_ERR_INVALID_ARG;
+    *out_ptr = nullptr;
+    if (bytes == 0) return TFHE_OK;
+    const hipError_t e = hipHostMalloc(out_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { g_create_error = std::string("tfhe_host_alloc: ") + hipGetErrorString(e); *out_ptr = nullptr; return TFHE_ERR_DEVICE; }
+    return TFHE_OK;
+}
+
+void tfhe_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
 int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out)
 {
@@ -381,6 +409,19 @@ extern "C" {
 
 static size_t bk_poly_count(const tfhe_params &p) { return (size_t)p.n * p.bs_l * (p.k + 1) * (p.k + 1); }
 
+// A key source may be a host buffer or (tfhe_keygen_cloud_key) a buffer on THIS context's device.  A buffer on another GPU
+// is refused: copying from it would depend on peer access between the two devices, which this library never enables.
+static int32_t check_key_source(tfhe_ctx *c, const void *p, const char *who)
+{
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return TFHE_OK; }       // an ordinary (unregistered) host pointer
+    if (at.type == hipMemoryTypeDevice && at.device != c->device)
+        return c->set_err(TFHE_ERR_DEVICE, "%s: the key buffer lives on device %d, this context on device %d: pass a host copy (peer access between GPUs is not assumed)",
+                          who, at.device, c->device);
+    return TFHE_OK;
+}
+
 static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
@@ -388,6 +429,7 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_bootstrap_key: context is multi-key, use tfhe_mk_load_*");
     if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return load_bk_common(c->kids[(size_t)k], host, bytes_in, is_c128); });
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int32_t rcp = check_key_source(c, host, "load_bootstrap_key"); if (rcp) return rcp; }
     const size_t npolys = bk_poly_count(c->P);
     const bool big = (c->P.N == kN2);
     if (c->d_bk) { (void)hipFree(c->d_bk); c->d_bk = nullptr; c->have_bk = false; }
@@ -451,6 +493,7 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_keyswitch_key: context is multi-key, use tfhe_mk_load_*");
     if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_load_keyswitch_key(c->kids[(size_t)k], ks); });
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int32_t rcp = check_key_source(c, ks, "load_keyswitch_key"); if (rcp) return rcp; }
     const size_t bytes = ks_word_count(c->P) * sizeof(int32_t);
     c->have_ks = false;
     if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; }
@@ -497,10 +540,10 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 // Generates the cloud key on the device (kernels_keygen.hpp) and loads it: the analogue of CloudKey(rng, secret_key)
 // (api.jl:111-127) with the secret material supplied by the caller.  Optionally copies the canonical Int32 arrays back.
 int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t *tlwe_key, double bs_noise_stddev,
-                              double ks_noise_stddev, uint64_t seed, int32_t *bk_out, int32_t *ks_out)
+                              double ks_noise_stddev, const uint32_t *seed, int32_t *bk_out, int32_t *ks_out)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    if (!lwe_key || !tlwe_key) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: NULL key pointer");
+    if (!lwe_key || !tlwe_key || !seed) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: NULL key or seed pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "keygen_cloud_key: context is multi-key (use tfhe_mk_expand_load_bootstrap_key)");
     if (!(bs_noise_stddev >= 0.0) || !(ks_noise_stddev >= 0.0)) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: negative noise parameter");
     tfhe_ctx *g = c->multi() ? c->kids[0] : c;             // a fan-out context generates on its first device
@@ -510,7 +553,13 @@ int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t
     const size_t Q = ks_words / (size_t)(P.n + 1), kN = (size_t)P.k * P.N;
     int32_t *d_lwe = nullptr, *d_tlwe = nullptr, *d_bk = nullptr, *d_ks = nullptr;
     double *d_noise = nullptr;
+    // secret material (the key bits, the raw noise) is zeroed before its memory goes back to the allocator, on the success and
+    // on every error path
     auto cleanup = [&]() {
+        if (d_lwe) (void)hipMemsetAsync(d_lwe, 0, (size_t)P.n * 4, g->stream);
+        if (d_tlwe) (void)hipMemsetAsync(d_tlwe, 0, kN * 4, g->stream);
+        if (d_noise) (void)hipMemsetAsync(d_noise, 0, (Q + 1) * sizeof(double), g->stream);
+        (void)hipStreamSynchronize(g->stream);
         (void)hipFree(d_lwe); (void)hipFree(d_tlwe); (void)hipFree(d_bk); (void)hipFree(d_ks); (void)hipFree(d_noise);
     };
     auto body = [&]() -> int32_t {
@@ -525,7 +574,7 @@ int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t
         A.lwe_key = d_lwe; A.tlwe_key = d_tlwe; A.bk = d_bk; A.ks = d_ks; A.ks_noise = d_noise; A.ks_mean = d_noise + Q;
         A.n = P.n; A.N = P.N; A.k = P.k; A.l = P.bs_l; A.beta = P.bs_log2_base; A.t = P.ks_t; A.ks_log2_base = P.ks_log2_base;
         A.bs_alpha = bs_noise_stddev; A.ks_alpha = ks_noise_stddev;
-        A.k0 = (uint32_t)seed; A.k1 = (uint32_t)(seed >> 32);
+        for (int i = 0; i < 6; i++) A.seed.w[i] = seed[i];
         const size_t samples = (size_t)P.n * P.bs_l * (P.k + 1);
         const size_t lds = kN * 4 + (size_t)P.k * (P.N / 32) * 4;
         hipLaunchKernelGGL(keygen::bk_kernel, dim3((unsigned)samples), dim3(256), lds, g->stream, A);
@@ -534,12 +583,21 @@ int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t
         hipLaunchKernelGGL(keygen::ks_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, g->stream, A, Q);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(g->stream));
-        if (bk_out) HIP_TRY(c, hipMemcpy(bk_out, d_bk, bk_words * 4, hipMemcpyDeviceToHost));
-        if (ks_out) HIP_TRY(c, hipMemcpy(ks_out, d_ks, ks_words * 4, hipMemcpyDeviceToHost));
-        // load: straight from the device buffers (one device), or through the loaders' fan-out (every device copies from this one)
-        int32_t rc = tfhe_load_bootstrap_key_i32(c, d_bk);
+        // A context with devices other than the generating one replicates through HOST copies (the caller's bk_out / ks_out,
+        // or a staging vector): the loaders then see plain host pointers on every device and nothing depends on peer
+        // access between GPUs being enabled.  One device: the loaders copy straight from the generated device buffers.
+        bool other_device = false;
+        if (c->multi())
+            for (const tfhe_ctx *k : c->kids) other_device = other_device || k->device != g->device;
+        std::vector<int32_t> stage_bk, stage_ks;
+        if (other_device && !bk_out) { stage_bk.resize(bk_words); bk_out = stage_bk.data(); }
+        if (other_device && !ks_out) { stage_ks.resize(ks_words); ks_out = stage_ks.data(); }
+        if (bk_out) HIP_TRY(c, hipMemcpyAsync(bk_out, d_bk, bk_words * 4, hipMemcpyDeviceToHost, g->stream));
+        if (ks_out) HIP_TRY(c, hipMemcpyAsync(ks_out, d_ks, ks_words * 4, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(c, hipStreamSynchronize(g->stream));
+        int32_t rc = tfhe_load_bootstrap_key_i32(c, other_device ? bk_out : d_bk);
         if (rc) return rc;
-        return tfhe_load_keyswitch_key(c, d_ks);
+        return tfhe_load_keyswitch_key(c, other_device ? ks_out : d_ks);
     };
     const int32_t rc = body();
     (void)hipSetDevice(g->device);
@@ -628,7 +686,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     if (c->P.k == 2) {
-        const size_t ldsk = 3 * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
+        const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);      // (no mirror blocks in this kernel: seven waves per CU)
 #define LAUNCH_K2(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, true>), dim3((unsigned)R), dim3(64), ldsk, s, a);  \
         else hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false>), dim3((unsigned)R), dim3(64), ldsk, s, a)
@@ -775,6 +833,13 @@ static int32_t leave_stream(tfhe_ctx *c, hipStream_t s)
     return TFHE_OK;
 }
 
+// every batch call records its four timing events into the next slot of the ring
+static void next_timing_slot(tfhe_ctx *c)
+{
+    c->ev = c->evring[c->timed_calls % tfhe_ctx::kTimingSlots];
+    c->timed_calls++;
+}
+
 static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
 {
     if (c->map_pending) {   // the previous call's H2D copy of the staging block must have been consumed
@@ -857,6 +922,7 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     const uint8_t *d_kind = (const uint8_t *)(d_td + Tn), *d_top = d_kind + R;
 
     const int n = c->P.n, kNn = c->P.k * c->P.N;
+    next_timing_slot(c);
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     if (R > 0) {
         HIP_TRY(c, c->bara.reserve(R * (size_t)(n + 1) * 4));
@@ -1020,6 +1086,29 @@ int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, 
                      c->stream);
 }
 
+static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                      int32_t *out, int64_t B, const bool (&need)[3]);
+
+// The twin of a one-device context: same device, its own stream / workspaces / events, the OWNER's keys (read-only on the
+// device).  Made on first use, dropped whenever the owner's keys are reloaded; the owner's tunables are copied at every use.
+static int32_t ensure_twin(tfhe_ctx *c)
+{
+    if (!c->twin) {
+        tfhe_ctx *t = nullptr;
+        const int32_t rc = tfhe_ctx_create(&c->P, c->device, &t);
+        if (rc) return c->set_err(rc, "gates_batch: second stream context: %s", g_create_error.c_str());
+        t->borrows_keys = true;
+        t->pipeline_min = -1;
+        c->twin = t;
+    }
+    tfhe_ctx *t = c->twin;
+    t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
+    t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
+    t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
+    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw;
+    return TFHE_OK;
+}
+
 // fan-out of a host-buffer batch call: kid r takes gates [bounds[r], bounds[r+1])
 static int32_t multi_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
                                  int32_t *out, int64_t B)
@@ -1048,13 +1137,51 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
     if (B == 0) return TFHE_OK;
     if (c->multi()) return multi_gates_batch(c, opcodes, in0, in1, in2, out, B);
     HIP_TRY(c, hipSetDevice(c->device));
+    // which operand arrays do the opcodes read at all?  (an array nobody reads is not uploaded)
+    bool need[3] = {false, false, false};
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: bad opcode %d at gate %lld", op, (long long)g);
+        need[0] = need[0] || op_has_a(op); need[1] = need[1] || op_has_b(op); need[2] = need[2] || op == TFHE_GATE_MUX;
+    }
+    if ((need[0] && !in0) || (need[1] && !in1) || (need[2] && !in2))
+        return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: an operand array required by the opcodes is NULL");
+    if (c->pipeline_min >= 0 && B >= c->pipeline_min && B >= 2 && !c->borrows_keys && !c->measure_margin && c->P.parties == 1 &&
+        c->have_bk && c->have_ks) {
+        // two halves, two streams: [upload B | compute A] then [compute B | download A] overlap
+        int64_t bounds[3];
+        shard_bounds_by_rotations(opcodes, B, 2, bounds);
+        if (bounds[1] > 0 && bounds[1] < B) {
+            const int32_t rct = ensure_twin(c);
+            if (rct) return rct;
+            const size_t n1 = (size_t)c->P.n + 1;
+            auto off = [&](const int32_t *p, int64_t g) { return p ? p + (size_t)g * n1 : nullptr; };
+            const int64_t h = bounds[1];
+            int32_t rc1 = TFHE_OK;
+            std::thread second([&] { rc1 = gates_batch_one_stream(c->twin, opcodes + h, off(in0, h), off(in1, h), off(in2, h), out + (size_t)h * n1, B - h, need); });
+            const int32_t rc0 = gates_batch_one_stream(c, opcodes, in0, in1, in2, out, h, need);
+            second.join();
+            if (rc1) return c->set_err(rc1, "gates_batch (second half): %s", c->twin->err.c_str());
+            if (rc0) return rc0;
+            c->last_rotations += c->twin->last_rotations;
+            return TFHE_OK;
+        }
+    }
+    return gates_batch_one_stream(c, opcodes, in0, in1, in2, out, B, need);
+}
+
+// one host-buffer batch on one context's stream: uploads, kernels, download, synchronise
+static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                      int32_t *out, int64_t B, const bool (&need)[3])
+{
+    HIP_TRY(c, hipSetDevice(c->device));
     // the staging buffers io[] are reused by this call: order the copies behind the previous call's kernels
     { const int32_t rc0 = enter_stream(c, c->stream); if (rc0) return rc0; }
     const size_t bytes = (size_t)B * (c->P.n + 1) * 4;
     const int32_t *hin[3] = {in0, in1, in2};
     int32_t *din[3] = {nullptr, nullptr, nullptr};
     for (int i = 0; i < 3; i++) {
-        if (!hin[i]) continue;
+        if (!hin[i] || !need[i]) continue;
         HIP_TRY(c, c->io[i].reserve(bytes));
         HIP_TRY(c, hipMemcpyAsync(c->io[i].p, hin[i], bytes, hipMemcpyHostToDevice, c->stream));
         din[i] = (int32_t *)c->io[i].p;
@@ -1087,6 +1214,7 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
     HIP_TRY(c, hipMemcpyAsync(c->io[0].p, in, in_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->bara.reserve((size_t)B * (n + 1) * 4));
     HIP_TRY(c, c->ext.reserve((size_t)B * (kNn + 1) * 4));
+    next_timing_slot(c);
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     hipLaunchKernelGGL(modswitch_kernel, dim3((unsigned)B), dim3(256), 0, s, (const int32_t *)c->io[0].p, (int32_t *)c->bara.p, n,
                        ilog2i(2 * c->P.N));
@@ -1143,6 +1271,7 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     HIP_TRY(c, c->map.reserve((size_t)B * 4));
     HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)B * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, c->io[3].reserve(out_bytes));
+    next_timing_slot(c);
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
@@ -1293,9 +1422,11 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
     if (c->d_mk_ks4) { (void)hipFree(c->d_mk_ks4); c->d_mk_ks4 = nullptr; }
     const int mode = (c->ks_variant == 4 && c->P.ks_t == 8) ? 4 : 3;
     if (mode == 3) {
+        // (every copy and kernel of a loader runs on the context's own stream: nothing here depends on what the NULL stream orders)
         HIP_TRY(c, hipMalloc((void **)&c->d_mk_ksp, (size_t)parties * rows * stride * 4));
-        HIP_TRY(c, hipMemset(c->d_mk_ksp, 0, (size_t)parties * rows * stride * 4));
-        HIP_TRY(c, hipMemcpy2D(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemsetAsync(c->d_mk_ksp, 0, (size_t)parties * rows * stride * 4, c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_mk_ksp, stride * 4, ks, n1 * 4, n1 * 4, (size_t)parties * rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->mk_ksp_words = rows * stride;
         c->ks_stride = (int)stride;
     } else {   // MFMA fragments per party (keyswitch_kernel_v4)
@@ -1306,7 +1437,7 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
         auto body = [&]() -> int32_t {
             HIP_TRY(c, hipMalloc(&c->d_mk_ks4, (size_t)parties * frags * 16));
             for (int p = 0; p < parties; p++) {
-                HIP_TRY(c, hipMemcpy(d_tmp, ks + (size_t)p * words, words * 4, hipMemcpyHostToDevice));
+                HIP_TRY(c, hipMemcpyAsync(d_tmp, ks + (size_t)p * words, words * 4, hipMemcpyHostToDevice, c->stream));
                 hipLaunchKernelGGL(ks4_prepare_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, c->stream, (const int32_t *)d_tmp,
                                    (i32x4 *)c->d_mk_ks4 + (size_t)p * frags, c->P.n, c->P.N, wtiles);
                 HIP_TRY(c, hipGetLastError());
@@ -1361,6 +1492,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     c->map_pending = true;
     const int32_t *d_gate = (const int32_t *)c->map.p;
     const uint8_t *d_kind = (const uint8_t *)(d_gate + B);
+    next_timing_slot(c);
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     // mk_gate_nand prologue (mk_gates.jl:8-10) = the NAND affine form over P*n+1 words, then mod-switch
     hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)B), dim3(256), 0, s, (const int32_t *)c->io[0].p, (const int32_t *)c->io[1].p,
@@ -1542,6 +1674,31 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
     return TFHE_OK;
 }
 
+int32_t tfhe_timing_history_ms(tfhe_ctx *c, int32_t which, float *ms, int32_t max_calls, int32_t *n_out)
+{
+    if (!c || !ms || !n_out || max_calls < 0) return TFHE_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (c->multi()) return c->set_err(TFHE_ERR_STATE, "timing_history: ask a one-device context (a multi-device context reports the slowest shard per call: tfhe_last_timing_ms)");
+    int a, b;
+    switch (which) {
+    case 0: a = 1; b = 2; break;
+    case 1: a = 2; b = 3; break;
+    case 2: a = 0; b = 3; break;
+    default: return c->set_err(TFHE_ERR_INVALID_ARG, "timing_history: which must be 0, 1 or 2");
+    }
+    const int64_t have = std::min<int64_t>(c->timed_calls, tfhe_ctx::kTimingSlots);
+    const int32_t n = (int32_t)std::min<int64_t>(have, max_calls);
+    if (n == 0) return TFHE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev[3]));          // the newest call has finished: so have the older ones on this context
+    for (int32_t i = 0; i < n; i++) {                   // oldest of the n first
+        hipEvent_t *set = c->evring[(c->timed_calls - n + i) % tfhe_ctx::kTimingSlots];
+        HIP_TRY(c, hipEventElapsedTime(ms + i, set[a], set[b]));
+    }
+    *n_out = n;
+    return TFHE_OK;
+}
+
 int64_t tfhe_last_rotation_count(const tfhe_ctx *c)
 {
     if (!c) return -1;
@@ -1572,7 +1729,8 @@ static int32_t read_diag(tfhe_ctx *c, double *worst, double *mhz)
     if (c->done_pending) HIP_TRY(c, hipEventSynchronize(c->done_ev));
     const size_t R = c->diag_rows;
     std::vector<unsigned long long> h(3 * R);
-    HIP_TRY(c, hipMemcpy(h.data(), c->diag.p, 3 * R * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->diag.p, 3 * R * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     double m = 0;
     for (size_t r = 0; r < R; r++) {
         double v;
@@ -1654,7 +1812,8 @@ int32_t tfhe_debug_phases(tfhe_ctx *c, unsigned long long *out64)
     if (!c || !out64 || c->multi() || !c->diag_rows) return TFHE_ERR_STATE;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
-    HIP_TRY(c, hipMemcpy(out64, (const char *)c->diag.p + c->diag_rows * 24, 64 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpyAsync(out64, (const char *)c->diag.p + c->diag_rows * 24, 64 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return TFHE_OK;
 }
 #endif
@@ -1688,6 +1847,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "pipeline_min")) { c->pipeline_min = value; return TFHE_OK; }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "n2048_rw")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");

@@ -76,28 +76,35 @@ class SecretKey:
     def __init__(self, rng, params: SchemeParameters):
         self.params = params
         self.key = LweKey(rng, params.lwe_size)
+        self.cloud_keygen_seed = None     # set by CloudKey(keygen="device"): it regenerates the key's noise, so it lives HERE
 
 
 class CloudKey:
     """api.jl:111-127.  Holds the flat key arrays; `engine(device)` gives the device context."""
 
     def __init__(self, rng, secret_key: SecretKey, keygen="host", device=0):
-        """keygen="host": numpy (the reference does this work on the host too); keygen="device": the secret bits and a
-        64-bit seed are drawn from `rng`, the key material is generated on GPU `device` (tfhe_keygen_cloud_key) and
-        the context that made it stays loaded as `engine(device)`."""
+        """keygen="host": numpy (the reference does this work on the host too); keygen="device": the TLWE key bits and a
+        seed of six 32-bit words (two for the public masks, four — 128 bits — for the noise) are drawn from `rng`, the key
+        material is generated on GPU `device` (tfhe_keygen_cloud_key) and the context that made it stays loaded as
+        `engine(device)`.  The seed is as secret as the secret key (it regenerates every noise term): it is kept on the
+        SecretKey object, never on this (public) one.  For real keys `rng` must be a cryptographic generator."""
         p = secret_key.params
         self.params = p
         self._engines = {}
         tlwe_key = TLweKey(rng, p.tlwe_polynomial_degree, p.tlwe_mask_size)
         if keygen == "device":
-            seed = int(rng.integers(0, 2**63))
+            seed = rng.integers(0, 2**32, 6, dtype=np.uint64).astype(np.uint32)
             e = _lib.Engine(p, device) if np.ndim(device) == 0 else _lib.Engine(p, devices=[int(d) for d in device])
-            self.bootstrap_key, self.keyswitch_key = e.keygen_cloud_key(secret_key.key.key, tlwe_key.key, p.bs_noise_stddev,
-                                                                        p.ks_noise_stddev, seed)
+            try:
+                self.bootstrap_key, self.keyswitch_key = e.keygen_cloud_key(secret_key.key.key, tlwe_key.key, p.bs_noise_stddev,
+                                                                            p.ks_noise_stddev, seed)
+            except Exception:
+                e.close()
+                raise
             self.bootstrap_key = self.bootstrap_key.reshape(p.lwe_size, p.bs_decomp_length, p.tlwe_mask_size + 1,
                                                             p.tlwe_mask_size + 1, p.tlwe_polynomial_degree)
             self._engines[device if np.ndim(device) == 0 else tuple(int(d) for d in device)] = e
-            self.keygen_seed = seed
+            secret_key.cloud_keygen_seed = seed
             return
         if keygen != "host":
             raise ValueError("keygen must be 'host' or 'device'")

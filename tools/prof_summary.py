@@ -47,7 +47,10 @@ for f in find("pmc_*/**/*counter_collection.csv"):
         if "blind_rotate" in k or "keyswitch" in k:
             print("  {:<60s} {:<28s} avg={:.6g} (n={})".format(k[:60], c, s / n, n))
 
-counters = {"_meta": {"command": cmd, "date": time.strftime("%Y-%m-%d"), "correction": "FETCH_SIZE x2 (gfx950 wide-load undercount), every --pmc group in its own run"}}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_source_sha16
+counters = {"_meta": {"command": cmd, "date": time.strftime("%Y-%m-%d"), "kernel_source_sha16": kernel_source_sha16(),
+                      "correction": "FETCH_SIZE x2 (gfx950 wide-load undercount), every --pmc group in its own run"}}
 for k, c in pmc.items():
     if not ("blind_rotate" in k or "keyswitch" in k):
         continue
