@@ -233,7 +233,9 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *ctx, const int32_t *in0, const int32_t
 
 /* Timing of the most recent batch call on ctx, from HIP events recorded on the stream the kernels
  * were launched on.  which: 0 = blind-rotate kernel(s), 1 = keyswitch kernel(s), 2 = whole batch
- * (prologue .. last kernel, device side).  Blocks until those kernels have finished. */
+ * (prologue .. last kernel, device side).  Blocks until those kernels have finished.  After a host-buffer call that ran as
+ * two halves on two streams (tfhe_gates_batch from "pipeline_min" gates up): from the start of the phase on the stream that
+ * started first to the later of the two streams' ends. */
 int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
 
 /* The same timing of up to the last 32 batch calls on a one-device ctx, oldest first, read in ONE go after the calls: a

@@ -20,7 +20,7 @@ DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 2>(MkBrArgs)", "void 
 # bytes per lane, nothing more.
 SMALL_RESIDUE = {r"void blind_rotate_kernel_n2048<[34], false, [124]>\(Br2048Args\)": 12,
                  r"void blind_rotate_kernel_n2048<[234], true, [124]>\(Br2048Args\)": 24,
-                 r"void mk_blind_rotate_kernel_g2<(4, 5|8, 8), false, 2>\(MkGenArgs\)": 16,
+                 r"void mk_blind_rotate_kernel_g2<(4, 5|8, 8), false, [24]>\(MkGenArgs\)": 24,
                  # k = 2 with l = 1: no shipped parameter set; two LDS addresses reloaded once per polynomial
                  r"void blind_rotate_kernel_k2<1, (true|false)>\(BrArgs\)": 16}
 

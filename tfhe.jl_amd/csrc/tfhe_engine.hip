@@ -127,6 +127,7 @@ struct tfhe_ctx {
     tfhe_ctx *twin = nullptr;
     bool borrows_keys = false;
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
+    bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
 
@@ -838,6 +839,7 @@ static void next_timing_slot(tfhe_ctx *c)
 {
     c->ev = c->evring[c->timed_calls % tfhe_ctx::kTimingSlots];
     c->timed_calls++;
+    c->last_call_two_streams = false;
 }
 
 static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
@@ -1164,6 +1166,7 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
             if (rc1) return c->set_err(rc1, "gates_batch (second half): %s", c->twin->err.c_str());
             if (rc0) return rc0;
             c->last_rotations += c->twin->last_rotations;
+            c->last_call_two_streams = true;
             return TFHE_OK;
         }
     }
@@ -1545,7 +1548,14 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         MkGenArgs ga;
         ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
         ga.prio_steps = a.prio_steps;
-        const int rw = 2;
+        // rotations per workgroup, in lockstep (they share their key fetches): "mkg_rw" 2 | 4, default 4 = one workgroup of
+        // eight waves per CU.  The 8-party key is 4.7 GB as spectra: with pairs the launch moves 2.2 TB beyond L2 (4.9 TB/s,
+        // L2 hit 59 %, profiles/r03/r03l_mk8: every pair streams the whole key for itself) and takes 450 ms; four rotations
+        // per workgroup halve that traffic: 388 ms.  4 parties: 73.1 vs 73.9 ms.  The DIAG instantiation exists for pairs only.
+        // (Measured dead end: pacing the workgroups of an XCD — a counter per XCD, one lane per workgroup waiting, bounded,
+        //  until its XCD's workgroups have all finished the step, so that they share key lines in their L2 — costs more in
+        //  waiting for the slowest of 32 than it saves: 8 parties 424 vs 403 ms, 4 parties 94 vs 80 ms on one device.)
+        const int rw = dg ? 2 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : 4;
         const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
@@ -1559,6 +1569,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 #define LAUNCH_G2_PL(PP, LL)                                                                                       \
         do {                                                                                                       \
             if (dg) LAUNCH_G2(PP, LL, true, 2);                                                                    \
+            else if (rw == 4) LAUNCH_G2(PP, LL, false, 4);                                                         \
             else LAUNCH_G2(PP, LL, false, 2);                                                                      \
         } while (0)
         if (NP == 4) LAUNCH_G2_PL(4, 5);
@@ -1671,6 +1682,13 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
     default: return c->set_err(TFHE_ERR_INVALID_ARG, "last_timing: which must be 0, 1 or 2");
     }
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    if (c->last_call_two_streams && c->twin && c->twin->timing_valid) {
+        // a two-stream call: from this (the first-started) stream's start of the phase to the LATER of the two streams' ends
+        float other = 0.f;
+        HIP_TRY(c, hipEventSynchronize(c->twin->ev[3]));
+        HIP_TRY(c, hipEventElapsedTime(&other, c->ev[a], c->twin->ev[b]));
+        if (other > *ms) *ms = other;
+    }
     return TFHE_OK;
 }
 

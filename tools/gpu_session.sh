@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: tests, bench line, other configs, profiles.  Usage: bash tools/gpu_session.sh <tag> [steps...]
-# steps (default all): test bench configs prof2 prof4a prof4b prof5
+# steps (default all): test bench configs prof2 prof4a prof4b prof5 (also: profmk4 profmk8 testall)
 # Every step runs under its own `timeout -k 10`; a step that times out or is killed ends the session (no further GPU step).
 TAG=${1:-run}; shift
 STEPS=${@:-test bench configs prof2 prof4a prof4b prof5}
@@ -24,6 +24,8 @@ for s in $STEPS; do
     prof4a)  run 600 prof4a bash tools/profile.sh ${TAG}_cfg4a tools/run_config.py --config 4a > gpurun_out/${TAG}_prof4a.log 2>&1; tail -12 gpurun_out/${TAG}_prof4a.log ;;
     prof4b)  run 600 prof4b bash tools/profile.sh ${TAG}_cfg4b tools/run_config.py --config 4b > gpurun_out/${TAG}_prof4b.log 2>&1; tail -12 gpurun_out/${TAG}_prof4b.log ;;
     prof5)   run 600 prof5 bash tools/profile.sh ${TAG}_cfg5 tools/run_config.py --config 5 > gpurun_out/${TAG}_prof5.log 2>&1; tail -12 gpurun_out/${TAG}_prof5.log ;;
+    profmk4) run 600 profmk4 bash tools/profile.sh ${TAG}_mk4 tools/run_config.py --config mk4 > gpurun_out/${TAG}_profmk4.log 2>&1; tail -12 gpurun_out/${TAG}_profmk4.log ;;
+    profmk8) run 900 profmk8 bash tools/profile.sh ${TAG}_mk8 tools/run_config.py --config mk8 > gpurun_out/${TAG}_profmk8.log 2>&1; tail -12 gpurun_out/${TAG}_profmk8.log ;;
     *) run 600 custom bash -c "$s" ;;
   esac
 done

@@ -88,6 +88,10 @@ def main():
     a = ap.parse_args()
     global OPTIONS
     OPTIONS = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.set]
+    if not any(k == "pipeline_min" for k, _ in OPTIONS):
+        # this tool times KERNELS: one launch per batch (the two-stream split of large host-buffer batches, which hides PCIe
+        # copies behind the other half's kernels, is what bench.py's value_pcie_inclusive measures; --set pipeline_min=4096 here)
+        OPTIONS.append(("pipeline_min", -1))
     want_diag = not a.no_diag
     if a.config == "1":
         res = single_key(tfhe.tfhe_parameters_80(), 1, max(a.reps, 20), 123, want_diag, "1: single gate_nand, tfhe_parameters_80")
