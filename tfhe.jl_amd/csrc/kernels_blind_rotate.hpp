@@ -366,10 +366,10 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
     }
 
-    int a_next = load_uniform_i32(bara) & (2 * kN - 1);
+    int a_next = bara[0] & (2 * kN - 1);      // (plain loads here: 0.6 % faster than through the scalar cache in this kernel, measured)
     for (int i = 0; i < P.n; i++) {
         const int a = a_next;
-        a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         wave_priority_step(i, P.prio_steps);
 
         cplx out[K1][8];
@@ -1655,7 +1655,10 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
     // (no wave_priority_* here: 22 KB of LDS per wave put 7 waves on a CU, so one SIMD has a single wave; measured 3 % slower with it)
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
-        const int a = load_uniform_i32(bara + i) & (2 * kN - 1);      // through the scalar cache: no vector register held for it
+        // (a plain load, not load_uniform_i32: with the exponent arriving through the scalar cache every wave of this kernel
+        //  takes the same time to the microsecond, and 4096 rotations on 7 x 256 wave slots then run as three strict rounds —
+        //  37.0 ms against 28.6 ms with the natural spread of the waves' progress; measured, profiles/r03/r03p_k2_exponent_load.txt)
+        const int a = bara[i] & (2 * kN - 1);
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + lane;
         cplx out[K1][8];
 #pragma unroll

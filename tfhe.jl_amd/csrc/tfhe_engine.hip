@@ -1541,6 +1541,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         }
 #undef LAUNCH_MK
         name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
+#ifndef TFHE_NO_G2      // (-DTFHE_NO_G2: quick development builds without the many-party two-wave kernel, 1 instead of 5 minutes)
     } else if (!c->mk_force_general && c->mkg_variant != 1 && ((NP == 4 && c->P.bs_l == 5) || (NP == 8 && c->P.bs_l == 8))) {
         // the shipped 4- and 8-party sets (mk_api.jl:16-34): compile-time (parties, l), two waves per rotation at two waves per
         // SIMD, accumulators in global memory.  LDS: two transposition buffers per rotation and the pass-B twiddle table;
@@ -1577,6 +1578,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 #undef LAUNCH_G2_PL
 #undef LAUNCH_G2
         name_kernel(c, "mk_blind_rotate_kernel_g2<%d,%d>", NP, c->P.bs_l);
+#endif
     } else {
         MkGenArgs ga;
         ga.diag = a.diag; ga.R = (int32_t)B; ga.bara = a.bara; ga.bk = a.bk; ga.ext = a.ext; ga.T = a.T; ga.g = a.g; ga.n = n; ga.mu = a.mu; ga.parties = NP; ga.L = c->P.bs_l;
