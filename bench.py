@@ -333,7 +333,7 @@ def main():
         fanout_ok = bool(np.array_equal(ref, out[lo:]))
 
     # --- extras on rank 0, outside the timed region ---------------------------------------------------
-    single_ms = pcie_value = pcie_pageable = clock_mhz = margin = None
+    single_ms = pcie_value = pcie_sync = pcie_pageable = clock_mhz = margin = None
     if rank == 0 and not args.fanout:
         if args.workload == "nand":   # "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1)
             one = np.zeros(1, np.uint8)
@@ -368,7 +368,28 @@ def main():
             t1 = time.perf_counter()
             for _ in range(reps):
                 eng.gates(ops, px, py, pz, out=pout)
-            pcie_value = B * reps / (time.perf_counter() - t1)
+            pcie_sync = B * reps / (time.perf_counter() - t1)
+            # ... and STREAMED: tfhe_gates_batch_submit / _wait, two batches in flight on two streams (the upload of one batch
+            # under the kernels of the other), as many steps as the timed loop above; every step's H2D + kernels + D2H is
+            # inside the timed region, results checked afterwards
+            sreps = max(4, args.steps)
+            pouts = [pout, tfhe.pinned_empty(hx.shape)]
+            tk, _ = eng.gates_submit(ops, px, py, pz, out=pouts[0]); eng.gates_wait(tk)        # (second stream's context made here)
+            tk, _ = eng.gates_submit(ops, px, py, pz, out=pouts[1]); eng.gates_wait(tk)
+            for o in pouts:
+                assert np.array_equal(o, out), "streamed host-buffer path differs from the device-buffer path"
+                o[:] = 0
+            t1 = time.perf_counter()
+            prev = None
+            for it in range(sreps):
+                tk, _ = eng.gates_submit(ops, px, py, pz, out=pouts[it & 1])
+                if prev is not None:
+                    eng.gates_wait(prev)
+                prev = tk
+            eng.gates_wait(prev)
+            pcie_value = B * sreps / (time.perf_counter() - t1)
+            for o in pouts:
+                assert np.array_equal(o, out), "streamed host-buffer path differs from the device-buffer path"
             # clock the blind-rotate kernel holds under this load + its rounding margin: DIAG instantiation of the
             # same kernel, >= 2 s of back-to-back launches first (MI355X_MICROARCH.md, DVFS give-back item 6)
             eng.set_option("measure_margin", 1)
@@ -423,8 +444,11 @@ def main():
             "every_rank_decrypts": all_ranks_decrypt,
             "fanout_matches_one_device": fanout_ok,
             "value_pcie_inclusive": pcie_value,
-            "value_pcie_inclusive_note": "the same step through tfhe_gates_batch: operands and result in page-locked host memory "
-                                         "(tfhe_host_alloc), H2D + kernels + D2H inside the timed region",
+            "value_pcie_inclusive_note": "the same steps streamed through tfhe_gates_batch_submit / _wait (two batches in flight, operands and "
+                                         "results in page-locked host memory from tfhe_host_alloc): every step's H2D + kernels + D2H inside "
+                                         "the timed region; _synchronous = one blocking tfhe_gates_batch per step (two half-batches on two "
+                                         "streams inside the call), _pageable = the same from ordinary numpy arrays",
+            "value_pcie_inclusive_synchronous": pcie_sync,
             "value_pcie_inclusive_pageable": pcie_pageable,
             "roofline": {
                 "bound": "hbm",
@@ -482,10 +506,12 @@ def main():
 
 def rocprof_symbol_prefix(kernel_name):
     """The engine's name for the launched kernel -> the start of its demangled symbol as rocprofv3 prints it:
-    "blind_rotate_kernel_v3<2,8,tw2reg>" is blind_rotate_kernel_v3<2, 8, true, ...>, "...v3<2,16>" is <2, 16, false, ...>."""
-    m = re.fullmatch(r"blind_rotate_kernel_v3<(\d+),(\d+)(,tw2reg)?>", kernel_name)
+    "blind_rotate_kernel_v3<2,8,tw2reg,rw4>" is blind_rotate_kernel_v3<2, 8, true, false, 4>, "...v3<2,8,tw2reg>" is
+    <2, 8, true, false, 1>, "...v3<2,16>" is <2, 16, false, false, 1> (template arguments: l, key values prefetched, pass-B
+    twiddles in registers, diagnostics, rotations per workgroup)."""
+    m = re.fullmatch(r"blind_rotate_kernel_v3<(\d+),(\d+)(,tw2reg)?(,rw4)?>", kernel_name)
     if m:
-        return f"blind_rotate_kernel_v3<{m.group(1)}, {m.group(2)}, {'true' if m.group(3) else 'false'},"
+        return f"blind_rotate_kernel_v3<{m.group(1)}, {m.group(2)}, {'true' if m.group(3) else 'false'}, false, {4 if m.group(4) else 1}>"
     return kernel_name.split("(")[0].rstrip(">").replace(",", ", ")
 
 

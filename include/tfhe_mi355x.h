@@ -170,6 +170,21 @@ void tfhe_host_free(void *ptr);
 int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                          const int32_t *in2, int32_t *out, int64_t B);
 
+/* The streaming form of tfhe_gates_batch, for a caller that feeds batch after batch from host memory: submit enqueues the
+ * upload, the kernels and the download of one batch and returns; wait blocks until that batch's `out` is complete.  A
+ * context runs up to two submitted batches at a time, on two streams taken in turn, so that the upload of batch i + 1
+ * runs under the kernels of batch i and the download of batch i under the kernels of batch i + 1 (the PCIe time of
+ * the synchronous call — ~0.7 ms of a 12 ms 4096-gate batch — disappears from the steady state); submitting a third
+ * batch first waits for the oldest.  in0/in1/in2/out must stay valid and untouched until the batch has been waited
+ * for, and should come from tfhe_host_alloc: the runtime stages copies from pageable memory synchronously, which
+ * overlaps nothing.  `opcodes` is read before submit returns.  *ticket identifies the batch for tfhe_gates_batch_wait
+ * (waiting twice, or for a batch a later submit already displaced, is harmless).  Contexts that cannot run two batches
+ * side by side (several devices, multi-key, measure_margin) complete the batch inside submit.  The timing queries
+ * below see only the batches that ran on the context's own stream (every other one). */
+int32_t tfhe_gates_batch_submit(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
+                                const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket);
+int32_t tfhe_gates_batch_wait(tfhe_ctx *ctx, int32_t ticket);
+
 /* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`
  * (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host except
  * for the upload of the B opcode bytes; results are ordered on `stream`.  The context's workspaces are shared by

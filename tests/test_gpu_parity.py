@@ -131,9 +131,9 @@ def test_edge_cases_and_errors(tfhe, keys80, eng80):
         tfhe.Engine(K.params, 99)                            # no such device
 
 
-@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8,tw2reg>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
+@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
 def test_full_batch_properties(tfhe, orc, keys80, eng80, B, kernel):
-    """BASELINE config 2 size (4096: two rounds of the one-wave kernel) and the chip-filling sizes of the two-wave kernel
+    """BASELINE config 2 size (4096: two rounds of the one-wave kernel, four rotations per workgroup in lockstep) and the chip-filling sizes of the two-wave kernel
     (1024: four workgroups on every CU, the waves of a workgroup swapping LDS buffers every step; 700: partly filled):
     every output decrypts to NAND; a sample of indices is bit-equal to the oracle; the batch is deterministic and
     independent of batch position."""
@@ -235,6 +235,61 @@ def test_ragged_batch_sizes(tfhe, orc, keys80, eng80, B):
     ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
     got = eng80.gates(ops, *ins)
     assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=16))
+
+
+def test_streamed_batches_equal_synchronous(tfhe, orc, keys80, eng80):
+    """tfhe_gates_batch_submit / _wait: six batches of different sizes and opcode mixes streamed two at a time from
+    page-locked buffers — every result bit-equal to the blocking call's; a third submit displaces (waits for) the oldest
+    batch; waiting twice, or for a displaced ticket, is harmless; a ticket nobody issued is an error."""
+    K = keys80
+    rng = np.random.default_rng(77)
+    names = ["NAND", "XOR", "MUX", "NOT", "ANDYN", "CONST1"]
+    jobs = []
+    for B in (300, 1, 2048, 77, 1500, 4):
+        ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
+        ins = []
+        for _ in range(3):
+            a = tfhe.pinned_empty((B, K.params.lwe_size + 1))
+            a[:] = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data
+            ins.append(a)
+        jobs.append((ops, ins, eng80.gates(ops, *ins)))
+    tickets, outs = [], []
+    for ops, ins, _ in jobs:                      # never waited for explicitly until the end: submits 3.. displace the oldest
+        t, o = eng80.gates_submit(ops, *ins)
+        tickets.append(t); outs.append(o)
+        assert t in (0, 1)
+    for t in tickets:
+        eng80.gates_wait(t)
+    eng80.gates_wait(tickets[0])
+    for (ops, ins, want), got in zip(jobs, outs):
+        assert np.array_equal(got, want)
+    with pytest.raises(tfhe.EngineError):
+        eng80.gates_wait(7)
+    # and interleaved with blocking calls on the same context
+    t, o = eng80.gates_submit(jobs[2][0], *jobs[2][1])
+    again = eng80.gates(jobs[0][0], *jobs[0][1])
+    eng80.gates_wait(t)
+    assert np.array_equal(o, jobs[2][2]) and np.array_equal(again, jobs[0][2])
+
+
+@pytest.mark.parametrize("B", [5, 1027, 2049])
+def test_lockstep_groups_ragged(tfhe, orc, keys80, eng80, B):
+    """blind_rotate_kernel_v3<...,rw4> (four rotations per workgroup, one barrier every four CMUX steps; the default from
+    2048 rotations up) on batch sizes that leave 3, 1 and 3 padding waves in the last workgroup: bit-equal to the oracle."""
+    K = keys80
+    rng = np.random.default_rng(B)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(2)]
+    ops = np.zeros(B, np.uint8)
+    for name, value in (("br_small", -1), ("br_tiny", -1), ("v3_rw", 4), ("pipeline_min", -1)):
+        eng80.set_option(name, value)
+    try:
+        got = eng80.gates(ops, *ins)
+        assert eng80.last_kernel_name() == "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"
+    finally:
+        for name, value in (("br_small", 1024), ("br_tiny", 8), ("v3_rw", 0), ("pipeline_min", 4096)):
+            eng80.set_option(name, value)
+    idx = np.unique(np.concatenate([np.arange(min(B, 8)), np.arange(max(0, B - 8), B)]))
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], ins[0][idx], ins[1][idx], nthreads=16))
 
 
 def test_maximum_lwe_size(tfhe, orc):

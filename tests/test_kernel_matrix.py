@@ -60,6 +60,11 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     _check(eng, K, x, f"blind_rotate_kernel_w2<{l}>", f"w2<{l}>")
     eng.set_option("br_small", -1)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},8,tw2reg>", "v3 default")
+    # four rotations per workgroup in lockstep (the default from 2048 rotations up): 6 rotations = one full group + one
+    # with two padding waves, which recompute the last rotation and store nothing
+    eng.set_option("v3_rw", 4)
+    _check(eng, K, x, f"blind_rotate_kernel_v3<{l},8,tw2reg,rw4>", "v3 lockstep groups")
+    eng.set_option("v3_rw", 0)
     eng.set_option("br_variant", 2)
     _check(eng, K, x, f"blind_rotate_kernel_v3<{l},16>", f"v3<{l},16>")
     eng.set_option("br_variant", 3)
@@ -175,7 +180,7 @@ def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
 
 # ---- BASELINE configurations at their stated batch sizes ----------------------------------------------------------
 def test_config4a_128bit_4096(tfhe, orc, keys128):
-    """BASELINE config 4a: tfhe_parameters_128 (api.jl:55-69), 4096 NAND on one GPU -> blind_rotate_kernel_v3<3,8,tw2reg>.
+    """BASELINE config 4a: tfhe_parameters_128 (api.jl:55-69), 4096 NAND on one GPU -> blind_rotate_kernel_v3<3,8,tw2reg,rw4>.
     Every output decrypts to NAND; 64 sampled rows equal the oracle word for word; DIAG run identical, margin < 0.25."""
     K = keys128
     eng = K.ck.engine(0)
@@ -185,7 +190,7 @@ def test_config4a_128bit_4096(tfhe, orc, keys128):
     x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
     ops = np.zeros(B, np.uint8)
     got = eng.gates(ops, x, y)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_v3<3,8,tw2reg>"
+    assert eng.last_kernel_name() == "blind_rotate_kernel_v3<3,8,tw2reg,rw4>"
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))

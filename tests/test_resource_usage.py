@@ -12,7 +12,8 @@ REPORT = os.path.join(ROOT, "tfhe.jl_amd", "build", "resource_usage.txt")
 # DIAG instantiations (rounding margin + in-kernel clock; run only under tfhe_set_option("measure_margin", 1)) that may
 # spill: the diagnostics add a live double and two 64-bit stamps to a kernel that is register-bound without them.
 DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 2>(MkBrArgs)", "void mk_blind_rotate_kernel_w2<4, true, 1>(MkBrArgs)",
-                  "void mk_blind_rotate_kernel_g2<4, 5, true, 2>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2>(MkGenArgs)"}
+                  "void mk_blind_rotate_kernel_g2<4, 5, true, 2>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2>(MkGenArgs)",
+                  "void blind_rotate_kernel_v3<1, 8, true, true, 4>(BrArgs)"}       # (l = 1: no shipped parameter set; 3 dwords)
 # Non-DIAG instantiations that keep ONE or TWO spilled dwords (an LDS address / a 64-bit key pointer reloaded once per CMUX
 # step of 3 000 - 30 000 instructions): the variants of these kernels that the compiler allocates without any scratch were
 # measured SLOWER (N = 2048: 46.5 ms with a scalar wave-half flag and no scratch against 44.6 ms with this one reload;

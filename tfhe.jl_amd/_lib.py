@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
     "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key", "tfhe_host_alloc", "tfhe_host_free",
-    "tfhe_timing_history_ms",
+    "tfhe_timing_history_ms", "tfhe_gates_batch_submit", "tfhe_gates_batch_wait",
 ]
 ABI_VERSION = 4
 
@@ -90,6 +90,9 @@ def load():
         lib.tfhe_host_free.restype = None
     lib.tfhe_gates_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64]
     lib.tfhe_gates_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp]
+    if hasattr(lib, "tfhe_gates_batch_submit"):
+        lib.tfhe_gates_batch_submit.argtypes = [vp, vp, vp, vp, vp, vp, i64, C.POINTER(i32)]
+        lib.tfhe_gates_batch_wait.argtypes = [vp, i32]
     lib.tfhe_bootstrap_batch.argtypes = [vp, i32, vp, vp, i64, i32]
     lib.tfhe_keyswitch_batch.argtypes = [vp, vp, vp, i64]
     lib.tfhe_mk_load_bootstrap_key_i32.argtypes = [vp, vp, i32]
@@ -162,6 +165,7 @@ class Engine:
         if rc != 0:
             raise EngineError(rc, self._lib.tfhe_last_error(None).decode())
         self._h = h
+        self._in_flight = {}
         self.device = self.devices[0]
 
     def close(self):
@@ -239,6 +243,31 @@ class Engine:
             raise ValueError(f"out must be a C-contiguous int32 array of shape {(B, self.n + 1)}")
         self._check(self._lib.tfhe_gates_batch(self._h, _ptr(ops), _ptr(in0), _ptr(in1), _ptr(in2), _ptr(out), B))
         return out
+
+    def gates_submit(self, opcodes, in0, in1=None, in2=None, out=None):
+        """Streaming form of gates(): enqueues the batch and returns (ticket, out) at once; `out` is complete after
+        gates_wait(ticket).  Two batches may be in flight (the upload of one under the kernels of the other); operands
+        and `out` should come from pinned_empty and must not be touched until the wait.  Arrays passed here are kept
+        alive until then; an operand that is not already a C-contiguous int32 array is copied first."""
+        ops = np.ascontiguousarray(opcodes, dtype=np.uint8)
+        B = ops.size
+        in0, in1, in2 = _i32c(in0), _i32c(in1), _i32c(in2)
+        for a in (in0, in1, in2):
+            if a is not None and a.shape != (B, self.n + 1):
+                raise ValueError(f"operand shape {a.shape}, expected {(B, self.n + 1)}")
+        if out is None:
+            out = pinned_empty((B, self.n + 1))
+        elif out.dtype != np.int32 or out.shape != (B, self.n + 1) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous int32 array of shape {(B, self.n + 1)}")
+        ticket = C.c_int32(-1)
+        self._check(self._lib.tfhe_gates_batch_submit(self._h, _ptr(ops), _ptr(in0), _ptr(in1), _ptr(in2), _ptr(out), B, C.byref(ticket)))
+        if ticket.value in (0, 1):
+            self._in_flight[ticket.value] = (in0, in1, in2, out)      # a displaced batch has been waited for by the library
+        return ticket.value, out
+
+    def gates_wait(self, ticket):
+        self._check(self._lib.tfhe_gates_batch_wait(self._h, int(ticket)))
+        self._in_flight.pop(int(ticket), None)
 
     def gates_dev(self, opcodes, d_in0, d_in1, d_in2, d_out, B, stream=0):
         """Device-pointer variant: operands are integer device addresses (e.g. torch tensor .data_ptr())."""

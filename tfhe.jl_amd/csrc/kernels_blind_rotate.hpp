@@ -114,6 +114,7 @@ struct BrArgs {
     int32_t n;
     int32_t mu;
     int32_t prio_steps;   // a wave lowers its issue priority 3 -> 2 -> 1 -> 0 over its first prio_steps CMUX steps (wave_priority_* below); 0: never
+    int32_t R;            // rotations in the batch
 };
 
 // Issue priority by progress.  The SIMD's arbiter favours the OLDER of its two waves: the first-placed wave of a SIMD runs
@@ -306,6 +307,9 @@ __device__ __forceinline__ void extract_mask_poly(int lane, const int32_t *img, 
     }
 }
 
+constexpr int kV3SyncEvery = 4;       // CMUX steps between the barriers of a lockstep group (1, 2, 4, 8, 16 measured: 11.62, 11.51, 11.49, 11.54, 11.53 ms)
+constexpr int kV3LdsBytes = 2 * kImg * 4 + (kXchElems + 64) * (int)sizeof(cplx);     // per rotation
+
 // v3: one wave per blind rotation at 2 waves/SIMD (<= 256 VGPRs, no AGPR/scratch spills).
 //   * pass-A twiddles (with the lane part of the twist folded in) resident in registers, pass-B twiddles
 //     in a 1 KB wave-private LDS table, the register part of the twist as compile-time constants:
@@ -313,12 +317,20 @@ __device__ __forceinline__ void extract_mask_poly(int lane, const int32_t *img, 
 //   * the accumulator lives only in LDS (read at rotate time and at the final add), each polynomial with its mirror
 //     block so that the rotation's signs and block offsets are scalar (rotate_sub3);
 //   * key spectra of the next transform prefetched into registers while the current FFT runs;
-//   * no s_barrier: wave-private LDS needs only compiler-level ordering;
+//   * wave-private LDS needs only compiler-level ordering, no s_barrier;
+//   * RW rotations per workgroup (RW = 1 or 4), one wave each with its own LDS region.  RW = 4: the four waves sit on the
+//     four SIMDs of a CU and meet at one s_barrier every kV3SyncEvery steps, so that they stream the SAME 64 KB of key per
+//     step at the same time: three of the four reads hit the CU's vector L1 and the exposed key latency (1.8 ms of 11.8
+//     when the loads are removed from the single-rotation workgroups) all but disappears (0.2 ms).  The other workgroup of
+//     the CU runs free of this one, so each SIMD still holds two waves in different phases.  4096 rotations: 11.5 vs
+//     11.8 ms (80-bit), 18.9 vs 19.5 ms (128-bit); below ~2000 rotations (one wave per SIMD, nothing to share the L1 with)
+//     the group only costs (1025 rotations: 5.5 vs 5.0 ms): the dispatcher uses RW = 4 from 2048 rotations up.  RW = 2
+//     puts the pair on one SIMD pair in the same phase: 13.4 ms; RW = 8: 12.0 ms (profiles/r03/r03r_*, r03t_*);
 //   * no branch on bara[i] == 0 (the step then adds exactly zero);
 //   * the first transform of a step writes the spectrum accumulators (a product, not a multiply-add): no zeroing.
 template <int L, int KPF /* key values prefetched per transform: 16 = whole chunk, 8 = half */, bool TW2REG = false /* pass-B twiddles in registers instead of LDS */,
-          bool MARGIN = false /* diagnostics: rounding margin + in-kernel clock (DiagArgs) */>
-__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
+          bool MARGIN = false /* diagnostics: rounding margin + in-kernel clock (DiagArgs) */, int RW = 1 /* rotations per workgroup */>
+__global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
 {
     constexpr int K1 = 2;
     // KPF == 8: the first half of a transform's key chunk is requested a transform ahead, the first KMID values of the
@@ -330,12 +342,16 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
     wave_priority_begin(P.prio_steps);
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+        const int wib = (RW > 1) ? wave_in_block() : 0;
+    char *smem = smem_all + (size_t)wib * kV3LdsBytes;
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][kImg]
     cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [kXchElems]
     cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
-    const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
+    const int lane = (RW > 1) ? lane_id() : (int)threadIdx.x;
+    size_t w = (size_t)blockIdx.x * RW + wib;
+    const bool padding = (RW > 1) && w >= (size_t)P.R;                    // recomputes the last rotation, stores nothing
+    if (padding) w = P.R - 1;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
@@ -371,6 +387,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         const int a = a_next;
         a_next = bara[i + 1] & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         wave_priority_step(i, P.prio_steps);
+        if (RW > 1 && (i % kV3SyncEvery) == 0) __builtin_amdgcn_s_barrier();
 
         cplx out[K1][8];
         int32_t temp[16];
@@ -506,6 +523,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_v3(BrArgs P)
         WAVE_LDS_FENCE();
     }
 
+    if (padding) return;
     int32_t *ext = P.ext + w * (kN + 1);
     extract_mask_poly(lane, acc_lds, ext);
     if (lane == 0) ext[kN] = acc_lds[kImg + kMir];
@@ -591,86 +609,6 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
     WAVE_LDS_FENCE();
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f[q]);
-    dft8<true>(x);
-}
-
-// The same transforms with the pass-A twiddles read from a table in LDS ([8][64], shared by the workgroup) instead of 32
-// registers per wave: for kernels whose steps are long (many parties: 30 to 81 transforms and 0.3 to 1.2 MB of key per
-// step) the 8 extra 16-byte reads per transform are ~1 % of a step, and the freed registers are what lets three spectrum
-// accumulators, a transform and two key polynomials in flight fit 256 registers at two waves per SIMD.
-// Values [FROM, TO) of a key polynomial (8 per lane, 1 KiB apart) from a UNIFORM base pointer: the base is pinned to scalar
-// registers and the lane enters as a 32-bit offset, so the loads take the "scalar base + vector offset + immediate" form and
-// no 64-bit per-lane address is ever built (those pairs were what the register-bound kernels spilled); the upper four values
-// are beyond the 4 KiB immediate range and use a second scalar base.
-template <int FROM, int TO>
-__device__ __forceinline__ void load_key_values(const cplx *poly, int lane, cplx (&k)[8])
-{
-    // (explicitly global: a pointer that has been through an asm operand is otherwise a generic one, and the loads become
-    //  flat_load — both counters, no counted waits)
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(1))) double2 *gptr;
-    gptr lo = (gptr)poly, hi = lo + 256;
-    asm volatile("" : "+s"(lo));
-    asm volatile("" : "+s"(hi));
-#pragma unroll
-    for (int k2 = FROM; k2 < TO; k2++) {
-        const double2 v = k2 < 4 ? lo[(unsigned)(k2 * 64 + lane)] : hi[(unsigned)((k2 - 4) * 64 + lane)];
-        k[k2] = mk(v.x, v.y);
-    }
-#else
-#pragma unroll
-    for (int k2 = FROM; k2 < TO; k2++) k[k2] = poly[k2 * 64 + lane];
-#endif
-}
-
-// (the table pointer passes through an opaque zero offset: the loads would otherwise be hoisted out of the caller's loops —
-//  the table never changes — straight back into the 32 registers this variant exists to free)
-template <typename T>
-__device__ __forceinline__ const T *opaque_table(const T *p)
-{
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    return p + z;
-}
-template <typename MID>
-__device__ __forceinline__ void fft_fwd_wave_mid_lt(int lane, cplx (&x)[8], const cplx *tw1f_lds, const cplx *tw2_lds, cplx *xch, MID &&mid)
-{
-    tw1f_lds = opaque_table(tw1f_lds);
-    dft8<false>(x);
-#pragma unroll
-    for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f_lds[q * 64 + lane]);
-    x1_store_a(lane, x, xch);
-    WAVE_LDS_FENCE();
-    x1_load_b(lane, x, xch);
-    dft8<false>(x);
-#pragma unroll
-    for (int q = 1; q < 8; q++) x[q] = cmul(x[q], tw2_lds[q * 8 + (lane & 7)]);
-    WAVE_LDS_FENCE();
-    x2_store(lane, x, xch);
-    WAVE_LDS_FENCE();
-    mid();
-    WAVE_LDS_FENCE();
-    x2_load(lane, x, xch);
-    WAVE_LDS_FENCE();
-    dft8<false>(x);
-}
-__device__ __forceinline__ void fft_inv_wave_lt(int lane, cplx (&x)[8], const cplx *tw1f_lds, const cplx *tw2_lds, cplx *xch)
-{
-    tw1f_lds = opaque_table(tw1f_lds);
-    dft8<true>(x);
-    x2_store(lane, x, xch);
-    WAVE_LDS_FENCE();
-    x2_load(lane, x, xch);
-#pragma unroll
-    for (int q = 1; q < 8; q++) x[q] = cmulc(x[q], tw2_lds[q * 8 + (lane & 7)]);
-    dft8<true>(x);
-    WAVE_LDS_FENCE();
-    x1_store_b(lane, x, xch);
-    WAVE_LDS_FENCE();
-    x1_load_a(lane, x, xch);
-    WAVE_LDS_FENCE();
-#pragma unroll
-    for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f_lds[q * 64 + lane]);
     dft8<true>(x);
 }
 

@@ -126,6 +126,9 @@ struct tfhe_ctx {
     // The second stream, its workspaces and its events belong to a twin context that BORROWS this context's keys.
     tfhe_ctx *twin = nullptr;
     bool borrows_keys = false;
+    bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
+    uint32_t submits = 0;
+    int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 2048 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
@@ -423,6 +426,14 @@ static int32_t check_key_source(tfhe_ctx *c, const void *p, const char *who)
     return TFHE_OK;
 }
 
+// Before a key buffer is freed or replaced: nothing this context (or its second-stream twin) enqueued may still be running.
+static void quiesce(tfhe_ctx *c)
+{
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->twin && c->twin->stream) (void)hipStreamSynchronize(c->twin->stream);
+    c->slot_busy[0] = c->slot_busy[1] = false;
+}
+
 static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
@@ -433,6 +444,7 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     { const int32_t rcp = check_key_source(c, host, "load_bootstrap_key"); if (rcp) return rcp; }
     const size_t npolys = bk_poly_count(c->P);
     const bool big = (c->P.N == kN2);
+    quiesce(c);
     if (c->d_bk) { (void)hipFree(c->d_bk); c->d_bk = nullptr; c->have_bk = false; }
     HIP_TRY(c, hipMalloc((void **)&c->d_bk, npolys * (size_t)(c->P.N / 2) * sizeof(cplx)));
     void *d_in = nullptr;
@@ -497,6 +509,7 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
     { const int32_t rcp = check_key_source(c, ks, "load_keyswitch_key"); if (rcp) return rcp; }
     const size_t bytes = ks_word_count(c->P) * sizeof(int32_t);
     c->have_ks = false;
+    quiesce(c);
     if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; }
     if (c->d_ksp) { (void)hipFree(c->d_ksp); c->d_ksp = nullptr; }
     if (c->d_ks4) { (void)hipFree(c->d_ks4); c->d_ks4 = nullptr; }
@@ -654,6 +667,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     a.n = c->P.n;
     a.mu = mu;
     a.prio_steps = (int32_t)((int64_t)c->P.n * c->br_prio_pct / 100);
+    a.R = (int32_t)R;
     const int L = c->P.bs_l;
     if (c->P.N == kN2) {
         Br2048Args b;
@@ -733,10 +747,20 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     if (brv >= 2) {
-        const size_t lds3 = 2 * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
-        const bool half = (brv == 3 || brv == 4), t2r = (brv == 4);
+        const size_t lds3 = kV3LdsBytes;
+        const bool half = (brv >= 3), t2r = (brv == 4);
+        // default variant: four rotations per workgroup in lockstep once the batch puts two waves
+        // on every SIMD (option v3_rw: 0 = by batch size, 1, 4)
+        const bool group = t2r && (c->v3_rw == 4 || (c->v3_rw == 0 && R >= 2048));
+#define LAUNCH_V3_GROUP(LL, DG)                                                                                    \
+        do {                                                                                                       \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_v3<LL, 8, true, DG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds3))); \
+            hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, DG, 4>), dim3((unsigned)((R + 3) / 4)), dim3(256), 4 * lds3, s, a); \
+        } while (0)
 #define LAUNCH_V3(LL)                                                                                              \
-        if (t2r && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
+        if (group && dg) LAUNCH_V3_GROUP(LL, true);                                                                \
+        else if (group) LAUNCH_V3_GROUP(LL, false);                                                                \
+        else if (t2r && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);     \
         else if (t2r) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, false>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
         else if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);   \
         else if (half) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
@@ -744,8 +768,9 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
         BR_CASES(LAUNCH_V3)
 #undef LAUNCH_V3
+#undef LAUNCH_V3_GROUP
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, t2r ? "blind_rotate_kernel_v3<%d,%d,tw2reg>" : "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
+        name_kernel(c, group ? "blind_rotate_kernel_v3<%d,%d,tw2reg,rw4>" : t2r ? "blind_rotate_kernel_v3<%d,%d,tw2reg>" : "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
         return TFHE_OK;
     }
 #ifdef TFHE_BUILD_BASELINE
@@ -1107,7 +1132,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw;
+    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw;
     return TFHE_OK;
 }
 
@@ -1173,9 +1198,9 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
     return gates_batch_one_stream(c, opcodes, in0, in1, in2, out, B, need);
 }
 
-// one host-buffer batch on one context's stream: uploads, kernels, download, synchronise
-static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
-                                      int32_t *out, int64_t B, const bool (&need)[3])
+// one host-buffer batch on one context's stream: uploads, kernels and download enqueued, nothing waited for
+static int32_t gates_batch_enqueue(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                   int32_t *out, int64_t B, const bool (&need)[3])
 {
     HIP_TRY(c, hipSetDevice(c->device));
     // the staging buffers io[] are reused by this call: order the copies behind the previous call's kernels
@@ -1193,7 +1218,66 @@ static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const
     int32_t rc = tfhe_gates_batch_dev(c, opcodes, din[0], din[1], din[2], (int32_t *)c->io[3].p, B, nullptr);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, c->io[3].p, bytes, hipMemcpyDeviceToHost, c->stream));
+    return TFHE_OK;
+}
+// ... and synchronised
+static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1, const int32_t *in2,
+                                      int32_t *out, int64_t B, const bool (&need)[3])
+{
+    const int32_t rc = gates_batch_enqueue(c, opcodes, in0, in1, in2, out, B, need);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+// Streaming form: batch i + 1 is submitted while batch i computes.  Two slots — the context's own stream and its twin's —
+// taken in turn: the upload of one batch runs under the kernels of the other and its download under the next one's.
+int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
+                                const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (!ticket) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: NULL ticket");
+    *ticket = 2;                                   // "complete": nothing to wait for
+    if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    // contexts that cannot run two batches side by side (several devices, multi-key, diagnostics, a borrowed key) run this one now
+    if (c->multi() || c->P.parties != 1 || c->measure_margin || c->borrows_keys || !c->have_bk || !c->have_ks)
+        return tfhe_gates_batch(c, opcodes, in0, in1, in2, out, B);
+    HIP_TRY(c, hipSetDevice(c->device));
+    bool need[3] = {false, false, false};
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: bad opcode %d at gate %lld", op, (long long)g);
+        need[0] = need[0] || op_has_a(op); need[1] = need[1] || op_has_b(op); need[2] = need[2] || op == TFHE_GATE_MUX;
+    }
+    if ((need[0] && !in0) || (need[1] && !in1) || (need[2] && !in2))
+        return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: an operand array required by the opcodes is NULL");
+    const int slot = (int)(c->submits & 1u);
+    if (slot == 1) { const int32_t rct = ensure_twin(c); if (rct) return rct; }
+    tfhe_ctx *t = slot ? c->twin : c;
+    if (c->slot_busy[slot]) {                      // a third batch: the oldest one's buffers and workspaces are about to be reused
+        HIP_TRY(c, hipStreamSynchronize(t->stream));
+        c->slot_busy[slot] = false;
+    }
+    const int32_t rc = gates_batch_enqueue(t, opcodes, in0, in1, in2, out, B, need);
+    if (rc) return slot ? c->set_err(rc, "gates_batch_submit: %s", t->err.c_str()) : rc;
+    c->submits++;
+    c->slot_busy[slot] = true;
+    *ticket = slot;
+    return TFHE_OK;
+}
+
+int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (ticket == 2) return TFHE_OK;
+    if (ticket != 0 && ticket != 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_wait: ticket %d was not issued by tfhe_gates_batch_submit", ticket);
+    if (!c->slot_busy[ticket]) return TFHE_OK;     // already waited for (or displaced by a later submit, which waited)
+    tfhe_ctx *t = ticket ? c->twin : c;
+    if (!t) return c->set_err(TFHE_ERR_STATE, "gates_batch_wait: the second stream's context is gone (keys reloaded while a batch was in flight)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(t->stream));
+    c->slot_busy[ticket] = false;
     return TFHE_OK;
 }
 
@@ -1868,6 +1952,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "pipeline_min")) { c->pipeline_min = value; return TFHE_OK; }
+    if (!strcmp(name, "v3_rw")) {
+        if (value != 0 && value != 1 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: v3_rw must be 0 (by batch size), 1 or 4");
+        c->v3_rw = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "n2048_rw")) {
         if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
