@@ -337,7 +337,11 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     // second half inside the transform (between the store and the load of its second transposition, where x[] is dead),
     // the rest after it.  Interleaved A/B on one device, 4096 rotations: l = 2: 12.86 ms against 13.07 with the whole chunk
     // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  The dispatcher picks by l.
+#ifdef TFHE_V3_KMID      // A/B builds only
+    constexpr int KMID = (KPF == 8) ? TFHE_V3_KMID : 0;
+#else
     constexpr int KMID = (KPF == 8) ? 4 : 0;
+#endif
     constexpr int F = K1 * L;
     wave_priority_begin(P.prio_steps);
     unsigned long long dg_t0 = 0, dg_r0 = 0;
