@@ -37,7 +37,7 @@ using TFHE: LweSample, LweParams, CloudKey, SecretKey, SchemeParameters, MKCloud
 using Random: AbstractRNG
 import Base.Broadcast: broadcastable, broadcasted
 
-export GpuCloudKey, GpuMKCloudKey, GpuLweArray, gates_batch, upload, download
+export GpuCloudKey, GpuMKCloudKey, GpuLweArray, gates_batch, gates_batch_async, PendingGates, upload, download
 
 const LIB = get(ENV, "TFHE_MI355X_LIB", joinpath(@__DIR__, "..", "tfhe.jl_amd", "lib", "libtfhe_mi355x.so"))
 
@@ -313,6 +313,62 @@ function gates_batch(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=nothing, z
         (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64),
         gck.ctx, opcodes, ptr(fx), ptr(fy), ptr(fz), out, B))
     unflatten(out, params)
+end
+
+# page-locked Int32 matrix (tfhe_host_alloc): the copies of a streamed batch are then single DMA transfers that overlap kernels
+function pinned_matrix(rows::Int, cols::Int)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:tfhe_host_alloc, LIB), Int32, (Csize_t, Ptr{Ptr{Cvoid}}), Csize_t(4 * rows * cols), p)
+    rc == 0 || error("tfhe_mi355x: tfhe_host_alloc failed (", rc, ")")
+    unsafe_wrap(Array, Ptr{Int32}(p[]), (rows, cols); own=false)
+end
+release_pinned(a::Array{Int32}) = ccall((:tfhe_host_free, LIB), Cvoid, (Ptr{Cvoid},), pointer(a))
+
+"""
+    t = gates_batch_async(gck, opcodes, xs, ys=nothing, zs=nothing)  ->  PendingGates
+    fetch(t)                                                         ->  Vector{LweSample}
+
+Streaming form of `gates_batch` (tfhe_gates_batch_submit / tfhe_gates_batch_wait): the call returns once the batch is
+enqueued; up to two batches run at a time, the upload of one under the kernels of the other, so a caller that feeds
+batch after batch pays no PCIe time in the steady state.  Operands are staged in page-locked buffers that `fetch` frees.
+"""
+mutable struct PendingGates
+    key::GpuCloudKey
+    ticket::Int32
+    buffers::Vector{Array{Int32}}     # page-locked operand copies + the result, alive until fetch
+    out::Array{Int32}
+    done::Bool
+end
+
+function gates_batch_async(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=nothing, zs=nothing)
+    B = length(opcodes)
+    B > 0 || error("gates_batch_async: empty batch")
+    n1 = gck.params.lwe_size + 1
+    stage(v) = v === nothing ? nothing : copyto!(pinned_matrix(n1, B), flatten(v))
+    fx, fy, fz = stage(xs), stage(ys), stage(zs)
+    out = pinned_matrix(n1, B)
+    ptr(a) = a === nothing ? Ptr{Int32}(C_NULL) : pointer(a)
+    ticket = Ref{Int32}(-1)
+    bufs = Array{Int32}[b for b in (fx, fy, fz, out) if b !== nothing]
+    rc = ccall((:tfhe_gates_batch_submit, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Ptr{Int32}),
+        gck.ctx, opcodes, ptr(fx), ptr(fy), ptr(fz), out, B, ticket)
+    if rc != 0
+        foreach(release_pinned, bufs)
+        check(gck.ctx, rc)
+    end
+    PendingGates(gck, ticket[], bufs, out, false)
+end
+
+function Base.fetch(t::PendingGates)
+    t.done && error("PendingGates: already fetched")
+    rc = ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)
+    res = rc == 0 ? unflatten(copy(t.out), LweParams(t.key.params.lwe_size)) : nothing
+    foreach(release_pinned, t.buffers)
+    empty!(t.buffers)
+    t.done = true
+    check(t.key.ctx, rc)
+    res
 end
 
 # one level of B gates on device-resident operands (tfhe_gates_level); host samples among them are uploaded first
