@@ -453,8 +453,10 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "bound_note": "judged figure (SURVEY §8d): algorithmic key bytes / launch time against HBM peak; the transformed key "
-                              "(32.8 MB) is shared by all resident rotations and is served from L2 / Infinity Cache, so real HBM "
-                              "traffic is ~1 % of this and the kernel is FP64-VALU bound: see roofline_secondary",
+                              "(32.8 MB) is shared by all resident rotations and is served from L1 / L2 / Infinity Cache, so real HBM "
+                              "traffic is ~1.5 % of this; the kernel is bound by instruction issue across FP64 VALU (floor: 64 % of the "
+                              "launch with everything else removed), the LDS transpositions and the key reads at two waves per SIMD "
+                              "(DESIGN.md 4.1, ablation table): see roofline_secondary",
                 "kernel": kernel_name,
                 "achieved": achieved / 1e9,
                 "peak": HBM_PEAK / 1e9,
@@ -541,7 +543,9 @@ def profile_counters(kernel_name, units_per_launch):
             stale += 1
             continue
         for k, v in d.items():
-            if k == "_meta" or v.get("workgroups_per_launch") not in (None, units_per_launch):
+            # (the profile must be of the same launch shape: one workgroup per rotation, or per four in the ",rw4" kernels)
+            per_wg = 4 if kernel_name.endswith(",rw4>") else 1
+            if k == "_meta" or v.get("workgroups_per_launch") not in (None, (units_per_launch + per_wg - 1) // per_wg):
                 continue
             if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k):
                 best = dict(v)

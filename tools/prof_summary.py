@@ -71,7 +71,7 @@ for k, c in pmc.items():
         e["valu_active_per_wave_cycle"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         e["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-    if k in grid: e["workgroups_per_launch"] = grid[k]      # blind-rotate kernels: one workgroup per rotation
+    if k in grid: e["workgroups_per_launch"] = grid[k]      # blind-rotate kernels: one workgroup per rotation (per four: v3<...,4>)
     counters[k] = e
 json.dump(counters, open(os.path.join(out, "counters.json"), "w"), indent=1)
 print("== derived (counters.json) ==")
