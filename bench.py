@@ -448,6 +448,7 @@ def main():
                                          "results in page-locked host memory from tfhe_host_alloc): every step's H2D + kernels + D2H inside "
                                          "the timed region; _synchronous = one blocking tfhe_gates_batch per step (two half-batches on two "
                                          "streams inside the call), _pageable = the same from ordinary numpy arrays",
+            "value_h2d_inclusive": pcie_value,      # SURVEY §8(d) config 2 asks for the host-to-device copy inside the timed region: the streamed figure has it (and the download too)
             "value_pcie_inclusive_synchronous": pcie_sync,
             "value_pcie_inclusive_pageable": pcie_pageable,
             "roofline": {
