@@ -1906,6 +1906,7 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
     if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
 }
 
+#ifndef TFHE_KERNEL_TEMPLATES_ONLY     // (the translation units that only instantiate kernel templates — mk_g2_*.hip — leave these out)
 // key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024
 __global__ __launch_bounds__(128) void bk_prepare_kernel_n2048(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out,
                                                              const cplx *__restrict__ tw1f2, const cplx *__restrict__ tw2)
@@ -2047,4 +2048,4 @@ __global__ __launch_bounds__(64) void bk_permute_c128_kernel(const cplx *__restr
         out[q * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
     }
 }
-
+#endif  // TFHE_KERNEL_TEMPLATES_ONLY

@@ -34,6 +34,9 @@ using namespace tfhe;
 
 #include "kernels_gates.hpp"
 #include "kernels_blind_rotate.hpp"
+#ifndef TFHE_NO_G2
+#include "mk_g2_launch.hpp"
+#endif
 #include "kernels_keyswitch.hpp"
 #include "kernels_keygen.hpp"
 
@@ -1645,22 +1648,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
         ga.acc = (int32_t *)c->mk_acc.p;
-#define LAUNCH_G2(PP, LL, DG, RWV)                                                                                 \
-        do {                                                                                                       \
-            if (ldsg2 > 64 * 1024)                                                                                 \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_g2<PP, LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg2)); \
-            hipLaunchKernelGGL((mk_blind_rotate_kernel_g2<PP, LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsg2, s, ga); \
-        } while (0)
-#define LAUNCH_G2_PL(PP, LL)                                                                                       \
-        do {                                                                                                       \
-            if (dg) LAUNCH_G2(PP, LL, true, 2);                                                                    \
-            else if (rw == 4) LAUNCH_G2(PP, LL, false, 4);                                                         \
-            else LAUNCH_G2(PP, LL, false, 2);                                                                      \
-        } while (0)
-        if (NP == 4) LAUNCH_G2_PL(4, 5);
-        else LAUNCH_G2_PL(8, 8);
-#undef LAUNCH_G2_PL
-#undef LAUNCH_G2
+        HIP_TRY(c, tfhe_launch_mk_g2(NP, dg, rw, nblk, ldsg2, s, ga));
         name_kernel(c, "mk_blind_rotate_kernel_g2<%d,%d>", NP, c->P.bs_l);
 #endif
     } else {
