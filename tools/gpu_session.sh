@@ -21,11 +21,11 @@ for s in $STEPS; do
     bench)   run 400 bench bash -c "python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err"; cat gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
     configs) for c in 1 2host 3 4a 4b 5 k2 mk4 mk8; do run 300 config_$c bash -c "python tools/run_config.py --config $c >> gpurun_out/${TAG}_configs.jsonl 2>> gpurun_out/${TAG}_configs.err"; done; cat gpurun_out/${TAG}_configs.jsonl ;;
     prof2)   run 600 prof2 bash tools/profile.sh ${TAG}_cfg2 > gpurun_out/${TAG}_prof2.log 2>&1; tail -25 gpurun_out/${TAG}_prof2.log ;;
-    prof4a)  run 600 prof4a bash tools/profile.sh ${TAG}_cfg4a tools/run_config.py --config 4a > gpurun_out/${TAG}_prof4a.log 2>&1; tail -12 gpurun_out/${TAG}_prof4a.log ;;
-    prof4b)  run 600 prof4b bash tools/profile.sh ${TAG}_cfg4b tools/run_config.py --config 4b > gpurun_out/${TAG}_prof4b.log 2>&1; tail -12 gpurun_out/${TAG}_prof4b.log ;;
-    prof5)   run 600 prof5 bash tools/profile.sh ${TAG}_cfg5 tools/run_config.py --config 5 > gpurun_out/${TAG}_prof5.log 2>&1; tail -12 gpurun_out/${TAG}_prof5.log ;;
-    profmk4) run 600 profmk4 bash tools/profile.sh ${TAG}_mk4 tools/run_config.py --config mk4 > gpurun_out/${TAG}_profmk4.log 2>&1; tail -12 gpurun_out/${TAG}_profmk4.log ;;
-    profmk8) run 900 profmk8 bash tools/profile.sh ${TAG}_mk8 tools/run_config.py --config mk8 > gpurun_out/${TAG}_profmk8.log 2>&1; tail -12 gpurun_out/${TAG}_profmk8.log ;;
+    prof4a)  run 600 prof4a bash tools/profile.sh ${TAG}_cfg4a tools/run_config.py --config 4a --reps 9 > gpurun_out/${TAG}_prof4a.log 2>&1; tail -12 gpurun_out/${TAG}_prof4a.log ;;
+    prof4b)  run 600 prof4b bash tools/profile.sh ${TAG}_cfg4b tools/run_config.py --config 4b --reps 9 > gpurun_out/${TAG}_prof4b.log 2>&1; tail -12 gpurun_out/${TAG}_prof4b.log ;;
+    prof5)   run 600 prof5 bash tools/profile.sh ${TAG}_cfg5 tools/run_config.py --config 5 --reps 9 > gpurun_out/${TAG}_prof5.log 2>&1; tail -12 gpurun_out/${TAG}_prof5.log ;;
+    profmk4) run 600 profmk4 bash tools/profile.sh ${TAG}_mk4 tools/run_config.py --config mk4 --reps 9 > gpurun_out/${TAG}_profmk4.log 2>&1; tail -12 gpurun_out/${TAG}_profmk4.log ;;
+    profmk8) run 900 profmk8 bash tools/profile.sh ${TAG}_mk8 tools/run_config.py --config mk8 --reps 6 > gpurun_out/${TAG}_profmk8.log 2>&1; tail -12 gpurun_out/${TAG}_profmk8.log ;;
     *) run 600 custom bash -c "$s" ;;
   esac
 done

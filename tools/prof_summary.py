@@ -22,9 +22,14 @@ for f in find("stats/**/*kernel_stats.csv"):
 print("== kernel trace: per-dispatch resources ==")
 grid = {}
 seen = set()
+durs = defaultdict(list)
 for f in find("stats/**/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "")
+        try:
+            durs[k].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        except Exception:
+            pass
         try:
             grid[k] = int(row.get("Grid_Size_X", row.get("Grid_Size", 0))) // max(1, int(row.get("Workgroup_Size_X", row.get("Workgroup_Size", 1))))
         except Exception:
@@ -34,6 +39,11 @@ for f in find("stats/**/*kernel_trace.csv"):
         print("  {:<70s} vgpr={} agpr={} sgpr={} lds={} scratch={} grid={} wg={}".format(
             k[:70], row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"),
             row.get("Scratch_Size"), row.get("Grid_Size_X", row.get("Grid_Size")), row.get("Workgroup_Size_X", row.get("Workgroup_Size"))))
+print("== blind-rotate launches in time order (ms): the first launch of a process runs before clocks and caches have settled ==")
+for k, v in durs.items():
+    if "blind_rotate" in k and len(v) > 1:
+        d = [x[1] / 1e6 for x in sorted(v)]
+        print("  {:<70s} first={:.3f} others: mean={:.3f} min={:.3f} max={:.3f} (n={})".format(k[:70], d[0], sum(d[1:]) / len(d[1:]), min(d[1:]), max(d[1:]), len(d) - 1))
 print("== PMC (average per dispatch) ==")
 pmc = defaultdict(dict)
 for f in find("pmc_*/**/*counter_collection.csv"):
