@@ -53,8 +53,8 @@ def br_flops(p):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--params", choices=["80", "128"], default="80")
     ap.add_argument("--workload", choices=["nand", "mixed"], default="nand",

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (on the GPU box, from the repo root):
-#   bash tools/profile.sh <tag>                                   profiles `python3 bench.py` at its default --steps / --warmup (the
+#   bash tools/profile.sh <tag>                                   profiles `python3 bench.py --gpus 1 --steps 20 --warmup 5` (the
 #                                                                 driver's command), without the CPU baseline and the DIAG runs
 #   bash tools/profile.sh <tag> tools/run_config.py --config 4a   profiles any other python program
 # Writes rocprofv3 kernel-trace stats and PMC passes (each in its own run, program directly after `--`) under
@@ -11,7 +11,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ $# -eq 0 ]; then
-  CMD="bench.py --no-cpu-baseline --no-diagnostics"
+  CMD="bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-diagnostics"
 else
   CMD="$@ --no-diag"
 fi
