@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include "tfhe_mi355x.h"
@@ -35,6 +36,10 @@ typedef void (*tfhe_ctx_destroy_t)(tfhe_ctx *);
 typedef const char *(*tfhe_last_error_t)(const tfhe_ctx *);
 typedef int32_t (*tfhe_keygen_cloud_key_t)(tfhe_ctx *, const int32_t *, const int32_t *, double, double, const uint32_t *, int32_t *, int32_t *);
 typedef int32_t (*tfhe_gates_batch_t)(tfhe_ctx *, const uint8_t *, const int32_t *, const int32_t *, const int32_t *, int32_t *, int64_t);
+typedef int32_t (*tfhe_gates_batch_submit_t)(tfhe_ctx *, const uint8_t *, const int32_t *, const int32_t *, const int32_t *, int32_t *, int64_t, int32_t *);
+typedef int32_t (*tfhe_gates_batch_wait_t)(tfhe_ctx *, int32_t);
+typedef int32_t (*tfhe_host_alloc_t)(size_t, void **);
+typedef void (*tfhe_host_free_t)(void *);
 
 int main(int argc, char **argv)
 {
@@ -42,6 +47,7 @@ int main(int argc, char **argv)
     void *lib = dlopen(argv[1], RTLD_NOW);
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
     LOAD(tfhe_device_count) LOAD(tfhe_ctx_create) LOAD(tfhe_ctx_destroy) LOAD(tfhe_last_error) LOAD(tfhe_keygen_cloud_key) LOAD(tfhe_gates_batch)
+    LOAD(tfhe_gates_batch_submit) LOAD(tfhe_gates_batch_wait) LOAD(tfhe_host_alloc) LOAD(tfhe_host_free)
     if (p_tfhe_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 4; }
 
     /* tfhe_parameters_80 (api.jl:30-45) */
@@ -86,6 +92,23 @@ int main(int argc, char **argv)
     }
     for (int g = 0; g < B; g++) ops[g] = (uint8_t)kinds[g / 8];
     if (p_tfhe_gates_batch(ctx, ops, in[0], in[1], in[2], out, B)) { fprintf(stderr, "gates_batch: %s\n", p_tfhe_last_error(ctx)); return 7; }
+
+    /* the streaming form: the same batch submitted three times, two in flight, results in page-locked buffers */
+    {
+        int32_t *sout[3] = {NULL, NULL, NULL};
+        int32_t ticket[3];
+        const size_t bytes = sizeof(int32_t) * B * (n + 1);
+        for (int k = 0; k < 3; k++)
+            if (p_tfhe_host_alloc(bytes, (void **)&sout[k])) { fprintf(stderr, "host_alloc failed\n"); return 8; }
+        for (int k = 0; k < 3; k++)
+            if (p_tfhe_gates_batch_submit(ctx, ops, in[0], in[1], in[2], sout[k], B, &ticket[k])) { fprintf(stderr, "submit: %s\n", p_tfhe_last_error(ctx)); return 8; }
+        for (int k = 0; k < 3; k++)
+            if (p_tfhe_gates_batch_wait(ctx, ticket[k])) { fprintf(stderr, "wait: %s\n", p_tfhe_last_error(ctx)); return 8; }
+        for (int k = 0; k < 3; k++) {
+            if (memcmp(sout[k], out, bytes)) { fprintf(stderr, "streamed batch %d differs from the blocking call\n", k); return 9; }
+            p_tfhe_host_free(sout[k]);
+        }
+    }
 
     int wrong = 0;
     for (int g = 0; g < B; g++) {
