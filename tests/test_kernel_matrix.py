@@ -100,6 +100,31 @@ def test_mask_size_2_kernel_every_l(tfhe, orc, l):
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(20 + l), 5, K.params.lwe_size + 1)
     _check(eng, K, x, f"blind_rotate_kernel_k2<{l}>", f"k2<{l}>")
+    # seven rotations per workgroup in lockstep (whole rounds of 1792 rotations by default): here 5 rotations + 2 padding
+    # waves, then 9 = one full group + one with five padding waves
+    eng.set_option("k2_rw", 7)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == f"blind_rotate_kernel_k2<{l},rw7>"
+    assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
+    x9 = _words(np.random.default_rng(30 + l), 9, K.params.lwe_size + 1)
+    assert np.array_equal(eng.bootstrap(MU, x9, with_keyswitch=False), K.oracle.bootstrap(MU, x9, with_keyswitch=False, nthreads=8))
+    eng.set_option("k2_rw", 0)
+    K.ck.close()
+
+
+def test_mask_size_2_balanced_rounds(tfhe, orc):
+    """The k = 2 dispatcher rule: 1792 + 300 rotations = two equally full rounds on a 256-CU device (workgroups of 5 and 4
+    rotations, the other waves of a group idling at the barriers); rows from the first, the last and the boundary
+    workgroups equal the oracle."""
+    K = _setup(tfhe, orc, 1024, 2, 2, BETA_OTHER[2], n=8)
+    eng = K.ck.engine(0)
+    R = 1792 + 300
+    x = np.repeat(_words(np.random.default_rng(77), 4, K.params.lwe_size + 1), (R + 3) // 4, axis=0)[:R].copy()
+    x[:, 0] += (np.arange(R, dtype=np.int64) << 20).astype(np.int32)          # distinct first exponents
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
+    idx = [0, 1, 4, 5, 6, 219, 220, 221, 224, 225, 1791, 1792, 1793, 2000, R - 2, R - 1]
+    assert np.array_equal(got[idx], K.oracle.bootstrap(MU, x[idx], with_keyswitch=False, nthreads=8))
     K.ck.close()
 
 

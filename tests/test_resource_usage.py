@@ -23,7 +23,7 @@ SMALL_RESIDUE = {r"void blind_rotate_kernel_n2048<[34], false, [124]>\(Br2048Arg
                  r"void blind_rotate_kernel_n2048<[234], true, [124]>\(Br2048Args\)": 24,
                  r"void mk_blind_rotate_kernel_g2<(4, 5|8, 8), false, [24]>\(MkGenArgs\)": 24,
                  # k = 2 with l = 1: no shipped parameter set; two LDS addresses reloaded once per polynomial
-                 r"void blind_rotate_kernel_k2<1, (true|false)>\(BrArgs\)": 16}
+                 r"void blind_rotate_kernel_k2<1, (true|false), [17]>\(BrArgs\)": 16}
 
 
 def _report():

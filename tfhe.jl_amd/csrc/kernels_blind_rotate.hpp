@@ -115,6 +115,7 @@ struct BrArgs {
     int32_t mu;
     int32_t prio_steps;   // a wave lowers its issue priority 3 -> 2 -> 1 -> 0 over its first prio_steps CMUX steps (wave_priority_* below); 0: never
     int32_t R;            // rotations in the batch
+    int32_t grp_big, grp_q;   // blind_rotate_kernel_k2<.., 7>: workgroups [0, grp_big) hold grp_q + 1 rotations, the others grp_q
 };
 
 // Issue priority by progress.  The SIMD's arbiter favours the OLDER of its two waves: the first-placed wave of a SIMD runs
@@ -1561,19 +1562,34 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 // mirrors would take its LDS from 22.5 to 23.3 KB per wave, i.e. from seven to six waves per CU — measured 29.0 vs 28.4 ms per 4096 rotations.)
 // Same algorithm as blind_rotate_kernel_v3 with a 3-polynomial accumulator: 3*L forward transforms and
 // 3 inverse transforms per step, out[co] += D[p, c] .* BK_i[p, c].a[co] for c, co in 0..2 (tgsw.jl:125-129).
-template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
+constexpr int kK2LdsBytes = 3 * kN * 4 + (kXchElems + 64) * (int)sizeof(cplx);      // per rotation
+template <int L, bool MARGIN = false, int RW = 1 /* rotations per workgroup, in lockstep (as blind_rotate_kernel_v3) */>
+__global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_k2(BrArgs P)
 {
     constexpr int K1 = 3;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int wib = (RW > 1) ? wave_in_block() : 0;
+    char *smem = smem_all + (size_t)wib * kK2LdsBytes;
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [K1][N]
     cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);
     cplx *tw2_lds = xch + kXchElems;
-    const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
+    const int lane = (RW > 1) ? lane_id() : (int)threadIdx.x;
+    // RW > 1: the batch is dealt out in whole rounds of one workgroup per CU, every workgroup with grp_q or grp_q + 1 (<= RW)
+    // rotations so that the rounds are equally full; the waves beyond a workgroup's count only keep the barriers company
+    size_t w = blockIdx.x;
+    if (RW > 1) {
+        const int g = (int)blockIdx.x;
+        const int cnt = g < P.grp_big ? P.grp_q + 1 : P.grp_q;
+        const size_t base = g < P.grp_big ? (size_t)g * (P.grp_q + 1) : (size_t)P.grp_big * (P.grp_q + 1) + (size_t)(g - P.grp_big) * P.grp_q;
+        if (wib >= cnt) {
+            for (int i = 0; i < P.n; i += kV3SyncEvery) __builtin_amdgcn_s_barrier();
+            return;
+        }
+        w = base + wib;
+    }
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
@@ -1601,6 +1617,7 @@ __global__ __launch_bounds__(64, 2) void blind_rotate_kernel_k2(BrArgs P)
         //  takes the same time to the microsecond, and 4096 rotations on 7 x 256 wave slots then run as three strict rounds —
         //  37.0 ms against 28.6 ms with the natural spread of the waves' progress; measured, profiles/r03/r03p_k2_exponent_load.txt)
         const int a = bara[i] & (2 * kN - 1);
+        if (RW > 1 && (i % kV3SyncEvery) == 0) __builtin_amdgcn_s_barrier();
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + lane;
         cplx out[K1][8];
 #pragma unroll

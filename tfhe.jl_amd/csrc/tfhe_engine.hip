@@ -131,6 +131,8 @@ struct tfhe_ctx {
     bool borrows_keys = false;
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
     uint32_t submits = 0;
+    int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU from 1024 rotations up
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 2048 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
@@ -273,6 +275,11 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         return (int32_t)TFHE_ERR_DEVICE;
     };
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    {
+        int cus = 0;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
+        c->cu_count = cus > 0 ? cus : 256;
+    }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     for (auto &set : c->evring)
         for (auto &ev : set)
@@ -704,7 +711,32 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     if (c->P.k == 2) {
-        const size_t ldsk = 3 * kN * 4 + (kXchElems + 64) * sizeof(cplx);      // (no mirror blocks in this kernel: seven waves per CU)
+        const size_t ldsk = kK2LdsBytes;      // (no mirror blocks in this kernel: seven rotations per CU)
+        // Up to seven rotations per workgroup in lockstep = one workgroup per CU: the k = 2 key is 73.7 MB of spectra, 144 KB
+        // per step and rotation, and independent waves stream it through the 4 MB L2 of their XCD at 77 % hits (58 GB beyond
+        // L2 per 4096 rotations, VALU busy 0.46: profiles/r03/r03k2_*); in lockstep the waves of a CU share every key line in
+        // its L1 and a full round of 1792 rotations takes 10.15 ms (0.81 of the roofline).  A partly filled round takes
+        // almost as long as a full one, so the batch is dealt out in ceil(R / 1792) EQUALLY full rounds: every workgroup
+        // gets floor or ceil of R / (rounds x CUs) rotations, its other waves idle at the barriers (4096 rotations: rounds
+        // of 6, 5 and 5 per CU).  Option k2_rw: 0 = this rule from 1024 rotations up, 1 = single-rotation workgroups, 7 = always.
+        const size_t cus = (size_t)c->cu_count;
+        const bool grouped = !dg && (c->k2_rw == 7 || (c->k2_rw == 0 && R >= 4 * cus));
+        if (grouped) {
+            const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
+            const size_t G = std::min(R, rounds * cus);                 // workgroups; fewer than one per CU only for tiny batches
+            a.grp_q = (int32_t)(R / G);
+            a.grp_big = (int32_t)(R % G);
+#define LAUNCH_K2(LL)                                                                                              \
+            do {                                                                                                   \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_k2<LL, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(7 * ldsk))); \
+                hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false, 7>), dim3((unsigned)G), dim3(448), 7 * ldsk, s, a); \
+            } while (0)
+            BR_CASES(LAUNCH_K2)
+#undef LAUNCH_K2
+            HIP_TRY(c, hipGetLastError());
+            name_kernel(c, "blind_rotate_kernel_k2<%d,rw7>", L);
+            return TFHE_OK;
+        }
 #define LAUNCH_K2(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, true>), dim3((unsigned)R), dim3(64), ldsk, s, a);  \
         else hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false>), dim3((unsigned)R), dim3(64), ldsk, s, a)
@@ -1135,7 +1167,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw;
+    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw;
     return TFHE_OK;
 }
 
@@ -1940,6 +1972,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "pipeline_min")) { c->pipeline_min = value; return TFHE_OK; }
+    if (!strcmp(name, "k2_rw")) {
+        if (value != 0 && value != 1 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1 or 7");
+        c->k2_rw = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "v3_rw")) {
         if (value != 0 && value != 1 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: v3_rw must be 0 (by batch size), 1 or 4");
         c->v3_rw = (int)value;
