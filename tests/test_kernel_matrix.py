@@ -321,6 +321,12 @@ def test_multi_device_context_equals_single(tfhe, orc, keys80):
     assert np.array_equal(e2.bootstrap(MU, x), e1.bootstrap(MU, x))
     assert np.array_equal(e2.keyswitch(ext), e1.keyswitch(ext))
     assert np.array_equal(e2.gates(np.zeros(0, np.uint8), np.zeros((0, 501), np.int32)), np.zeros((0, 501), np.int32))
+    # the streaming entry points on a context that cannot run two batches side by side: the batch completes inside submit
+    ops = np.zeros(300, np.uint8)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, 300).astype(bool)).data for _ in range(2)]
+    t, o = e2.gates_submit(ops, *ins)
+    assert t == 2 and np.array_equal(o, e1.gates(ops, *ins))
+    e2.gates_wait(t)
     with pytest.raises(tfhe.EngineError):
         e2.gates(np.array([0, 99, 0], np.uint8), x[:3], x[:3])                  # bad opcode: nothing runs
     with pytest.raises(tfhe.EngineError):
