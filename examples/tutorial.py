@@ -29,12 +29,28 @@ def prepare():
     return secret_key, cloud_key, ciphertext1, ciphertext2
 
 
-def encrypted_minimum_circuit(nb_bits=16):
+def encrypted_minimum_circuit(nb_bits=16, log_depth=False):
+    """log_depth=False: the reference's circuit gate for gate (a 16-deep XNOR -> MUX ripple, then 16 parallel MUXes:
+    48 gates, 80 blind rotations, 18 levels).  log_depth=True: the same function with the ripple replaced by a reduction
+    tree — more gates (63, 94 blind rotations) in 7 levels, for an engine whose cost is per LEVEL, not per gate."""
     c = tfhe.Circuit()
     a, b = c.inputs(nb_bits), c.inputs(nb_bits)
-    tmps1 = c.constant(False)                                           # :52
-    for i in range(nb_bits):                                            # :54-56 with encrypted_compare_bit :42-45
-        tmps1 = c.mux(c.xnor(a[i], b[i]), tmps1, a[i])
+    if not log_depth:
+        tmps1 = c.constant(False)                                       # :52
+        for i in range(nb_bits):                                        # :54-56 with encrypted_compare_bit :42-45
+            tmps1 = c.mux(c.xnor(a[i], b[i]), tmps1, a[i])
+    else:
+        # One ripple step is s -> MUX(t_i, s, a_i) with t_i = XNOR(a_i, b_i): "keep s if the bits agree, else take a_i".
+        # Such maps compose: (later o earlier) keeps s iff both do (AND of the selectors) and otherwise yields
+        # MUX(t_later, const_earlier, const_later).  Reduce the 16 steps pairwise, then apply the result to s = false:
+        # MUX(T, false, A) = (not T) and A.
+        steps = [(c.xnor(a[i], b[i]), a[i]) for i in range(nb_bits)]    # (selector, constant), least significant first
+        while len(steps) > 1:
+            nxt = [(c.and_(hi[0], lo[0]), c.mux(hi[0], lo[1], hi[1])) for lo, hi in zip(steps[0::2], steps[1::2])]
+            if len(steps) % 2:
+                nxt.append(steps[-1])
+            steps = nxt
+        tmps1 = c.andny(steps[0][0], steps[0][1])
     c.set_outputs([c.mux(tmps1, b[i], a[i]) for i in range(nb_bits)])   # :60
     return c
 
@@ -54,4 +70,11 @@ if __name__ == "__main__":
     t0 = time.perf_counter()
     answer = process(cloud_key, ciphertext1, ciphertext2)
     print(f"(48 gates, 80 blind rotations, 18 levels: {1e3 * (time.perf_counter() - t0):.1f} ms incl. key upload)")
+    verify(secret_key, answer)
+    tree = encrypted_minimum_circuit(16, log_depth=True)
+    inputs = tfhe.LweSampleArray(np.concatenate([ciphertext1.data, ciphertext2.data]))
+    tree.run(cloud_key, inputs)
+    t0 = time.perf_counter()
+    answer = tree.run(cloud_key, inputs)
+    print(f"(reduction tree: {len(tree.levels())} levels: {1e3 * (time.perf_counter() - t0):.1f} ms)")
     verify(secret_key, answer)

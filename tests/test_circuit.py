@@ -59,3 +59,22 @@ def test_tutorial_circuit_on_device(tfhe, orc, keys80):
         eng.gates_level(np.array([0, 0], np.uint8), np.array([0, 40], np.int32), np.array([1, 1], np.int32), None, np.array([40, 41], np.int32))
     with pytest.raises(tfhe.EngineError):   # out of range
         eng.gates_level(np.array([0], np.uint8), np.array([0], np.int32), np.array([10**6], np.int32), None, np.array([40], np.int32))
+
+
+@pytest.mark.gpu
+def test_log_depth_minimum_circuit_on_device(tfhe, orc, keys80):
+    """examples/tutorial.py, log_depth=True: the comparator ripple of examples/tutorial.jl:42-56 replaced by a reduction tree
+    (7 levels instead of 18); same function, checked against the oracle word for word and against min() on decrypted bits."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from tutorial import encrypted_minimum_circuit
+    K = keys80
+    c = encrypted_minimum_circuit(16, log_depth=True)
+    assert [len(l) for l in c.levels()] == [16, 16, 8, 4, 2, 1, 16]
+    rng = np.random.default_rng(5)
+    for a, b in [(2017, 42), (42, 2017), (65535, 65535), (0, 1)] + [tuple(int(v) for v in rng.integers(0, 65536, 2)) for _ in range(3)]:
+        bits = [(a >> i) & 1 == 1 for i in range(16)] + [(b >> i) & 1 == 1 for i in range(16)]
+        enc = tfhe.encrypt(K.rng, K.sk, bits)
+        res = c.run(K.ck, enc)
+        assert sum(int(v) << i for i, v in enumerate(tfhe.decrypt(K.sk, res))) == min(a, b), (a, b)
+    assert np.array_equal(res.data, _oracle_eval(c, K.oracle, orc, enc.data))

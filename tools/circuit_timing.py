@@ -17,3 +17,7 @@ for ops, a, b, c, o in circ.level_arrays():
     eng.gates_level(ops, a, b, c, o)
 eng.wires_download(0, 1)
 print(f"18 levels device time + launches: {(time.perf_counter()-t0)*1e3:.1f} ms")
+tree = encrypted_minimum_circuit(16, log_depth=True)
+for it in range(3):
+    t0 = time.perf_counter(); out = tree.run(ck, inputs); dt = time.perf_counter() - t0
+    print(f"log-depth variant ({len(tree.levels())} levels, {sum(len(l) for l in tree.levels())} gates) run {it}: {dt*1e3:.1f} ms -> {bits_to_int(tfhe.decrypt(sk, out))}")
