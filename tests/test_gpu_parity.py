@@ -286,7 +286,7 @@ def test_lockstep_groups_ragged(tfhe, orc, keys80, eng80, B):
         got = eng80.gates(ops, *ins)
         assert eng80.last_kernel_name() == "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"
     finally:
-        for name, value in (("br_small", 1024), ("br_tiny", 8), ("v3_rw", 0), ("pipeline_min", 4096)):
+        for name, value in (("br_small", 1024), ("br_tiny", -2), ("v3_rw", 0), ("pipeline_min", 4096)):
             eng80.set_option(name, value)
     idx = np.unique(np.concatenate([np.arange(min(B, 8)), np.arange(max(0, B - 8), B)]))
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], ins[0][idx], ins[1][idx], nthreads=16))

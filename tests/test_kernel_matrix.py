@@ -78,13 +78,14 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
         eng.bootstrap(MU, x, with_keyswitch=False)
     assert ei.value.code == 2
     eng.set_option("br_variant", 0)
-    # the switch between the two kernels is by batch size: 1025 rotations take the one-wave kernel without any option
-    eng.set_option("br_tiny", 8)
+    # the switches between the kernels are by batch size, without any option: up to one rotation per CU (256 on an MI355X)
+    # every transform is split over two waves, up to 1024 rotations a rotation takes two waves, beyond that one
+    eng.set_option("br_tiny", -2)
     big = np.repeat(x[2:3], 1025, axis=0)
     big[:, 0] += np.arange(1025, dtype=np.int32) << 21       # distinct first exponents
-    idx = [0, 1, 7, 8, 511, 512, 1023, 1024]
+    idx = [0, 1, 7, 8, 255, 256, 511, 512, 1023, 1024]
     want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8)
-    for rows, kernel in ((8, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (9, f"blind_rotate_kernel_w2<{l}>"),
+    for rows, kernel in ((256, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (257, f"blind_rotate_kernel_w2<{l}>"),
                          (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, f"blind_rotate_kernel_v3<{l},8,tw2reg>")):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())

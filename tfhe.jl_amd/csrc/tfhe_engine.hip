@@ -85,7 +85,9 @@ struct tfhe_ctx {
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
-    int64_t br_tiny = 8;         // batches of at most this many rotations split every transform over two waves (-1: never);
+    int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
+                                 //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
+                                 //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
     int br_variant = 0;          // 0 = default (4), 1 = round-1 baseline kernel (-DTFHE_BUILD_BASELINE builds only), 2 = v3 with the whole key chunk
                                  // requested a transform ahead, 3 = v3 with half of it ahead and the rest inside / after the transform,
@@ -747,7 +749,8 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         return TFHE_OK;
     }
     const int brv = c->br_variant ? c->br_variant : 4;                     // 0 = default: half key chunk ahead + pass-B twiddles in registers
-    if ((c->br_tiny >= 0 && (int64_t)R <= c->br_tiny) && brv >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
+    const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
+    if ((tiny >= 0 && (int64_t)R <= tiny) && brv >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
