@@ -100,10 +100,11 @@ def test_mask_size_2_kernel_every_l(tfhe, orc, l):
     K = _setup(tfhe, orc, 1024, 2, l, BETA_OTHER[l], n=8)
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(20 + l), 5, K.params.lwe_size + 1)
+    eng.set_option("k2_rw", 1)                # single-rotation workgroups (and their DIAG instantiation)
     _check(eng, K, x, f"blind_rotate_kernel_k2<{l}>", f"k2<{l}>")
-    # seven rotations per workgroup in lockstep (whole rounds of 1792 rotations by default): here 5 rotations + 2 padding
-    # waves, then 9 = one full group + one with five padding waves
-    eng.set_option("k2_rw", 7)
+    # the default: up to seven rotations per workgroup in lockstep, dealt out in equally full rounds of one workgroup per
+    # CU — 5 rotations = five workgroups of one rotation and six idle waves each, then 9
+    eng.set_option("k2_rw", 0)
     got = eng.bootstrap(MU, x, with_keyswitch=False)
     assert eng.last_kernel_name() == f"blind_rotate_kernel_k2<{l},rw7>"
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))

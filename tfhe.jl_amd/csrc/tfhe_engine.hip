@@ -119,11 +119,13 @@ struct tfhe_ctx {
     DevBuf bara, ext, map, io[4], diag, abar, mk_acc;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
-    int n2048_rw = 2;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 1|2))
+    int n2048_rw = 0;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 0|1|2|4); 0 = one up to
+                                   //  one rotation per CU — the pair would leave half the CUs idle: 7.9 vs 9.0 ms at 64 rotations — two beyond)
     int mkg_rw = 0;                // any-party kernel: rotations per workgroup, in lockstep (0: two; otherwise a cap, at most 4 and what fits in LDS)
     int mkg_variant = 0;           // 4- / 8-party shipped sets: 0 = two-wave kernel with compile-time (parties, l), 1 = the any-party kernel
     int mkg_acc = -1;              // any-party kernel: accumulators in LDS (0) / in global memory (1) / by party count (-1: global above 4 parties)
-    int mk_rw = 2;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 1|2))
+    int mk_rw = 0;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 0|1|2); 0 = one
+                                   //  up to one rotation per CU (single mk_gate_nand 11.7 vs 13.7 ms), two beyond)
     int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     // Host-buffer batches of at least `pipeline_min` gates are cut in two rotation-balanced halves that run on two streams of
@@ -134,7 +136,7 @@ struct tfhe_ctx {
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
     uint32_t submits = 0;
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
-    int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU from 1024 rotations up
+    int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 2048 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
@@ -686,7 +688,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
         // n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation per workgroup)
-        const int rw = c->n2048_rw;
+        const int rw = c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);
         const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
 #define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
@@ -720,9 +722,9 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         // its L1 and a full round of 1792 rotations takes 10.15 ms (0.81 of the roofline).  A partly filled round takes
         // almost as long as a full one, so the batch is dealt out in ceil(R / 1792) EQUALLY full rounds: every workgroup
         // gets floor or ceil of R / (rounds x CUs) rotations, its other waves idle at the barriers (4096 rotations: rounds
-        // of 6, 5 and 5 per CU).  Option k2_rw: 0 = this rule from 1024 rotations up, 1 = single-rotation workgroups, 7 = always.
+        // of 6, 5 and 5 per CU).  Option k2_rw: 0 / 7 = this rule, 1 = single-rotation workgroups.
         const size_t cus = (size_t)c->cu_count;
-        const bool grouped = !dg && (c->k2_rw == 7 || (c->k2_rw == 0 && R >= 4 * cus));
+        const bool grouped = !dg && (c->k2_rw == 7 || c->k2_rw == 0);     // (never slower than single-rotation workgroups: 6.7 vs 6.9 ms at 64 rotations, 6.8 vs 7.6 at 512)
         if (grouped) {
             const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
             const size_t G = std::min(R, rounds * cus);                 // workgroups; fewer than one per CU only for tiny batches
@@ -1636,7 +1638,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
         // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four)
-        const int rw = c->mk_rw;
+        const int rw = c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
         const size_t lds2 = (size_t)rw * ((NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         a.R = (int32_t)B;
@@ -1678,7 +1680,9 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         // (Measured dead end: pacing the workgroups of an XCD — a counter per XCD, one lane per workgroup waiting, bounded,
         //  until its XCD's workgroups have all finished the step, so that they share key lines in their L2 — costs more in
         //  waiting for the slowest of 32 than it saves: 8 parties 424 vs 403 ms, 4 parties 94 vs 80 ms on one device.)
-        const int rw = dg ? 2 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : 4;
+        // (up to two rotations per CU the pairs win: 4 parties 54 vs 69 ms at 512 rotations, 62 vs 79 ms for a single gate;
+        //  8 parties 298 vs 374 ms at 256 — profiles/r03/r03j_*)
+        const int rw = dg ? 2 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : ((size_t)B <= 2 * (size_t)c->cu_count ? 2 : 4);
         const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
@@ -1987,7 +1991,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "n2048_rw")) {
-        if (value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 1, 2 or 4");
+        if (value != 0 && value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 0 (by batch size), 1, 2 or 4");
         c->n2048_rw = (int)value;
         return TFHE_OK;
     }
@@ -2007,7 +2011,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_rw")) {
-        if (value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_rw must be 1 or 2");
+        if (value != 0 && value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_rw must be 0 (by batch size), 1 or 2");
         c->mk_rw = (int)value;
         return TFHE_OK;
     }
