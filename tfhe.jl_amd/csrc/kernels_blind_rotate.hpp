@@ -325,7 +325,7 @@ constexpr int kV3LdsBytes = 2 * kImg * 4 + (kXchElems + 64) * (int)sizeof(cplx);
 //     when the loads are removed from the single-rotation workgroups) all but disappears (0.2 ms).  The other workgroup of
 //     the CU runs free of this one, so each SIMD still holds two waves in different phases.  4096 rotations: 11.5 vs
 //     11.8 ms (80-bit), 18.9 vs 19.5 ms (128-bit); below ~2000 rotations (one wave per SIMD, nothing to share the L1 with)
-//     the group only costs (1025 rotations: 5.5 vs 5.0 ms): the dispatcher uses RW = 4 from 2048 rotations up.  RW = 2
+//     the group only costs (1100 rotations: 5.6 vs 5.1 ms; break-even at ~1500): the dispatcher uses RW = 4 from 1536 rotations up.  RW = 2
 //     puts the pair on one SIMD pair in the same phase: 13.4 ms; RW = 8: 12.0 ms (profiles/r03/r03r_*, r03t_*);
 //   * no branch on bara[i] == 0 (the step then adds exactly zero);
 //   * the first transform of a step writes the spectrum accumulators (a product, not a multiply-add): no zeroing.

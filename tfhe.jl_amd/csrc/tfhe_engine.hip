@@ -137,7 +137,7 @@ struct tfhe_ctx {
     uint32_t submits = 0;
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
-    int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 2048 rotations up
+    int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
@@ -790,8 +790,8 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         const size_t lds3 = kV3LdsBytes;
         const bool half = (brv >= 3), t2r = (brv == 4);
         // default variant: four rotations per workgroup in lockstep once the batch puts two waves
-        // on every SIMD (option v3_rw: 0 = by batch size, 1, 4)
-        const bool group = t2r && (c->v3_rw == 4 || (c->v3_rw == 0 && R >= 2048));
+        // on most SIMDs (option v3_rw: 0 = by batch size, 1, 4)
+        const bool group = t2r && (c->v3_rw == 4 || (c->v3_rw == 0 && R >= 1536));      // (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
 #define LAUNCH_V3_GROUP(LL, DG)                                                                                    \
         do {                                                                                                       \
             HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_v3<LL, 8, true, DG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds3))); \
