@@ -545,7 +545,7 @@ def profile_counters(kernel_name, units_per_launch):
             continue
         for k, v in d.items():
             # (the profile must be of the same launch shape: one workgroup per rotation, or per four in the ",rw4" kernels)
-            per_wg = 4 if kernel_name.endswith(",rw4>") else 1
+            per_wg = 4 if kernel_name.endswith(",rw4>") else 2 if kernel_name.endswith(",rw2>") else 1
             if k == "_meta" or v.get("workgroups_per_launch") not in (None, (units_per_launch + per_wg - 1) // per_wg):
                 continue
             if re.search(r"(?<![A-Za-z0-9_])" + re.escape(key), k):

@@ -131,10 +131,11 @@ def test_edge_cases_and_errors(tfhe, keys80, eng80):
         tfhe.Engine(K.params, 99)                            # no such device
 
 
-@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"), (1024, "blind_rotate_kernel_w2<2>"), (700, "blind_rotate_kernel_w2<2>")])
+@pytest.mark.parametrize("B,kernel", [(4096, "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"), (1024, "blind_rotate_kernel_w2<2,rw2>"), (700, "blind_rotate_kernel_w2<2>"), (400, "blind_rotate_kernel_w2<2,rw2>")])
 def test_full_batch_properties(tfhe, orc, keys80, eng80, B, kernel):
     """BASELINE config 2 size (4096: two rounds of the one-wave kernel, four rotations per workgroup in lockstep) and the chip-filling sizes of the two-wave kernel
-    (1024: four workgroups on every CU, the waves of a workgroup swapping LDS buffers every step; 700: partly filled):
+    (1024: two pairs of rotations on every CU, the waves of a rotation swapping LDS buffers every step; 700: partly filled,
+    single rotations; 400: at most one pair per CU):
     every output decrypts to NAND; a sample of indices is bit-equal to the oracle; the batch is deterministic and
     independent of batch position."""
     K = keys80

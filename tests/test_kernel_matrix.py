@@ -83,10 +83,10 @@ def test_single_key_kernels_n1024_every_l(tfhe, orc, l):
     eng.set_option("br_tiny", -2)
     big = np.repeat(x[2:3], 1025, axis=0)
     big[:, 0] += np.arange(1025, dtype=np.int32) << 21       # distinct first exponents
-    idx = [0, 1, 7, 8, 255, 256, 511, 512, 1023, 1024]
+    idx = [0, 1, 7, 8, 255, 256, 511, 512, 698, 699, 1023, 1024]
     want = K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8)
-    for rows, kernel in ((256, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (257, f"blind_rotate_kernel_w2<{l}>"),
-                         (1024, f"blind_rotate_kernel_w2<{l}>"), (1025, f"blind_rotate_kernel_v3<{l},8,tw2reg>")):
+    for rows, kernel in ((256, f"blind_rotate_kernel_h2<{l}>" if l <= 3 else f"blind_rotate_kernel_w2<{l}>"), (257, f"blind_rotate_kernel_w2<{l},rw2>"),
+                         (700, f"blind_rotate_kernel_w2<{l}>"), (1024, f"blind_rotate_kernel_w2<{l},rw2>"), (1025, f"blind_rotate_kernel_v3<{l},8,tw2reg>")):
         got = eng.bootstrap(MU, big[:rows], with_keyswitch=False)
         assert eng.last_kernel_name() == kernel, (rows, eng.last_kernel_name())
         sel = [j for j, r in enumerate(idx) if r < rows]

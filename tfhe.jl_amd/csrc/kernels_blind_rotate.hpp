@@ -1215,21 +1215,28 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_g2(MkGenAr
 // (Measured dead end: one wave per (component, digit) — 2 l waves, one forward transform each — is no faster, 1.94 vs
 //  1.89 ms per gate: a lone wave issues FP64 at about half the SIMD's rate, and four waves transposing at once run into
 //  the CU's LDS store bandwidth, so every transform gets slower as the step gets shorter.)
-template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
+constexpr int kW2LdsBytes = 2 * kImg * 4 + (2 * kXchElems + 64) * (int)sizeof(cplx);     // per rotation
+// RW rotations per workgroup (RW = 2: the step barrier then spans both rotations, which keeps them in lockstep and lets
+// them share their key reads in the CU's L1, as in the other kernels; a padding rotation repeats the last one and stores nothing)
+template <int L, bool MARGIN = false, int RW = 1>
+__global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_w2(BrArgs P)
 {
     constexpr int K1 = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int wib = wave_in_block();
+    char *smem = smem_all + (size_t)(RW > 1 ? (wib >> 1) : 0) * kW2LdsBytes;
     int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [2][kXchElems]: the waves swap them every step
     cplx *tw2_lds = xch_all + 2 * kXchElems;                                     // [8][8]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = wave_in_block();                                              // wave = owned polynomial
+    const int tid = threadIdx.x & 127, lane = tid & 63;
+    const int wv = RW > 1 ? (wib & 1) : wib;                                      // wave = owned polynomial
     int32_t *acc_lds = acc_all + wv * kImg;
-    const size_t w = blockIdx.x;
+    size_t w = (size_t)blockIdx.x * RW + (RW > 1 ? (wib >> 1) : 0);
+    const bool padding = RW > 1 && w >= (size_t)P.R;
+    if (padding) w = (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
@@ -1302,6 +1309,7 @@ __global__ __launch_bounds__(128, 2) void blind_rotate_kernel_w2(BrArgs P)
     STAMP_FLUSH(P.diag, wv);
     __syncthreads();
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    if (padding) return;
     int32_t *ext = P.ext + w * (kN + 1);
     if (wv == 0) extract_mask_poly(lane, acc_all, ext);
     else if (lane == 0) ext[kN] = acc_all[kImg + kMir];

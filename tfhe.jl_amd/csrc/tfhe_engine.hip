@@ -136,6 +136,7 @@ struct tfhe_ctx {
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
     uint32_t submits = 0;
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+    int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
@@ -776,14 +777,20 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     }
     if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && brv >= 2) {
         // 27.4 KB of LDS and < 256 registers per wave: four workgroups per CU, 1024 rotations resident at two waves per SIMD
-        const size_t ldsw = 2 * kImg * 4 + (2 * kXchElems + 64) * sizeof(cplx);
+        const size_t ldsw = kW2LdsBytes;
+        // two rotations per workgroup (lockstep through the step barrier, key reads shared in L1) when that fills the CUs evenly: from
+        // more than one rotation up to one pair per CU (300 rotations 2.26 vs 2.58 ms, 512: 2.29 vs 2.57; 128-bit set 3.64 vs 4.10) and at (nearly) two
+        // pairs per CU (1024: 3.35 vs 3.41; 128-bit 5.36 vs 5.57); in between single rotations spread better (700: 2.95 vs 3.29)
+        const size_t cus2 = 2 * (size_t)c->cu_count;
+        const bool pairs = !dg && (c->w2_rw == 2 || (c->w2_rw == 0 && ((R > cus2 / 2 && R <= cus2) || R > 2 * cus2 - cus2 / 8)));
 #define LAUNCH_W2(LL)                                                                                              \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, true>), dim3((unsigned)R), dim3(128), ldsw, s, a); \
+        else if (pairs) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false, 2>), dim3((unsigned)((R + 1) / 2)), dim3(256), 2 * ldsw, s, a); \
         else hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false>), dim3((unsigned)R), dim3(128), ldsw, s, a)
         BR_CASES(LAUNCH_W2)
 #undef LAUNCH_W2
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, "blind_rotate_kernel_w2<%d>", L);
+        name_kernel(c, pairs ? "blind_rotate_kernel_w2<%d,rw2>" : "blind_rotate_kernel_w2<%d>", L);
         return TFHE_OK;
     }
     if (brv >= 2) {
@@ -1172,7 +1179,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw;
+    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
     return TFHE_OK;
 }
 
@@ -1979,6 +1986,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "measure_margin")) { c->measure_margin = value != 0; return TFHE_OK; }
     if (!strcmp(name, "pipeline_min")) { c->pipeline_min = value; return TFHE_OK; }
+    if (!strcmp(name, "w2_rw")) {
+        if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: w2_rw must be 0 (by batch size), 1 or 2");
+        c->w2_rw = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "k2_rw")) {
         if (value != 0 && value != 1 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1 or 7");
         c->k2_rw = (int)value;
