@@ -132,11 +132,20 @@ def test_mask_size_2_balanced_rounds(tfhe, orc):
 
 @pytest.mark.parametrize("l", [1, 2, 3, 4])
 def test_n2048_kernel_every_l(tfhe, orc, l):
-    """blind_rotate_kernel_n2048<l> (synthetic N = 2048, BASELINE config 4b's shape)."""
+    """blind_rotate_kernel_n2048x<l> (synthetic N = 2048, BASELINE config 4b's shape): the rotated words of a polynomial are
+    computed by one wave and handed to the other (round 4); one, two and four rotations per workgroup (5 rotations = padded
+    groups); blind_rotate_kernel_n2048<l>, where both waves rotate both polynomials, stays selectable."""
     K = _setup(tfhe, orc, 2048, 1, l, BETA_OTHER[l], n=8)
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(40 + l), 5, K.params.lwe_size + 1)
-    _check(eng, K, x, f"blind_rotate_kernel_n2048<{l}>", f"n2048<{l}>")
+    _check(eng, K, x, f"blind_rotate_kernel_n2048x<{l},rw1>", f"n2048x<{l}>")
+    for rw in (2, 4):
+        eng.set_option("n2048_rw", rw)
+        _check(eng, K, x, f"blind_rotate_kernel_n2048x<{l},rw{rw}>", f"n2048x<{l},rw{rw}>")
+    eng.set_option("n2048_variant", 1)
+    _check(eng, K, x, f"blind_rotate_kernel_n2048<{l},rw4>", f"n2048<{l},rw4>")
+    eng.set_option("n2048_rw", 0)
+    _check(eng, K, x, f"blind_rotate_kernel_n2048<{l},rw1>", f"n2048<{l}>")
     K.ck.close()
 
 
@@ -199,7 +208,13 @@ def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
     y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
     if which in ("4party", "8party"):
         # default for the shipped shapes: two waves per rotation, compile-time (parties, l); DIAG instantiation included
-        _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_g2<{parties},{l}>")
+        # (4 parties: the accumulator images in LDS, round 4; option mkg_acc 1 keeps them in global memory as at 8 parties)
+        _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_g2<{parties},{l}" + (",acc=lds>" if parties == 4 else ">"))
+        if parties == 4:
+            eng.set_option("mkg_acc", 1)
+            want = o.mk_gate_nand(x, y, nthreads=4)
+            assert np.array_equal(eng.mk_gate_nand(x, y), want) and eng.last_kernel_name() == "mk_blind_rotate_kernel_g2<4,5>"
+            eng.set_option("mkg_acc", -1)
         eng.set_option("mkg_variant", 1)
     _mk_check(eng, o, x, y, f"mk_blind_rotate_kernel_general(P={parties},L={l}" + (",acc=global)" if parties > 4 else ")"))
     ck.close()
@@ -229,7 +244,7 @@ def test_config4a_128bit_4096(tfhe, orc, keys128):
 
 
 def test_config4b_synthetic_n2048_4096(tfhe, orc):
-    """BASELINE config 4b: synthetic N = 2048 (n = 630, l = 3, beta = 7), 4096 NAND -> blind_rotate_kernel_n2048<3>."""
+    """BASELINE config 4b: synthetic N = 2048 (n = 630, l = 3, beta = 7), 4096 NAND -> blind_rotate_kernel_n2048x<3,rw2>."""
     from conftest import KeySet
     from test_oracle import synthetic_2048
     K = KeySet(tfhe, orc, synthetic_2048(tfhe), seed=2048)
@@ -240,7 +255,7 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
     x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
     ops = np.zeros(B, np.uint8)
     got = eng.gates(ops, x, y)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_n2048<3>"
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n2048x<3,rw2>"
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
     idx = rng.choice(B, 64, replace=False)
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
@@ -248,6 +263,9 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
         assert np.array_equal(eng.gates(ops, x, y), got)   # waves of a rotation would show as a run-to-run difference)
     eng.set_option("br_prio_pct", 0)                 # without the issue-priority schedule: same words
     assert np.array_equal(eng.gates(ops, x, y), got)
+    eng.set_option("n2048_variant", 1)               # both waves rotating both polynomials (the round-3 kernel): same words
+    assert np.array_equal(eng.gates(ops, x, y), got)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n2048<3,rw2>"
     eng.set_option("br_prio_pct", 90)
     eng.set_option("measure_margin", 1)
     again = eng.gates(ops[:256], x[:256], y[:256])

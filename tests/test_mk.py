@@ -126,7 +126,7 @@ def test_mk_gpu_parity_many_parties(orc, tfhe, which, parties, n):
     assert np.array_equal(got, want)
     if (parties, p.bs_decomp_length) in ((4, 5), (8, 8)):
         # the shipped 4- / 8-party shapes take the two-wave kernel with compile-time (parties, l) ...
-        assert eng.last_kernel_name() == f"mk_blind_rotate_kernel_g2<{parties},{p.bs_decomp_length}>"
+        assert eng.last_kernel_name() == f"mk_blind_rotate_kernel_g2<{parties},{p.bs_decomp_length}" + (",acc=lds>" if parties == 4 else ">")
         assert np.array_equal(eng.mk_gate_nand(x[:1], y[:1]), want[:1])  # ... a single rotation with its padding partner
         eng.set_option("mkg_variant", 1)                                  # ... and the any-party kernel stays the fallback
         got = eng.mk_gate_nand(x, y)
@@ -173,7 +173,7 @@ def test_device_rgsw_expand_equals_host(orc, tfhe, which, parties, n):
 def test_mk_four_party_full_size_sample(orc, tfhe):
     """mktfhe_parameters_4party at its shipped size (mk_api.jl:16-22: n = 500, l = 5, beta = 6): the key is expanded on
     the device (RGSW.Expand), downloaded for the oracle, and a sample of NAND gates is compared word for word; every
-    output decrypts (2000 CMUX steps, 30 forward transforms each, through mk_blind_rotate_kernel_g2<4,5>)."""
+    output decrypts (2000 CMUX steps, 30 forward transforms each, through mk_blind_rotate_kernel_g2<4,5,acc=lds>)."""
     p = tfhe.mktfhe_parameters_4party
     rng = np.random.default_rng(4444)
     sks = [tfhe.SecretKey(rng, p) for _ in range(4)]
@@ -184,7 +184,7 @@ def test_mk_four_party_full_size_sample(orc, tfhe):
     m1, m2 = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     x, y = tfhe.mk_encrypt(rng, sks, m1), tfhe.mk_encrypt(rng, sks, m2)
     got = eng.mk_gate_nand(x, y)
-    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_g2<4,5>"
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_g2<4,5,acc=lds>"
     assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.95
     o = orc.Oracle(p.lwe_size, 1024, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=4)
     o.load_bootstrap_key(ck.bootstrap_key)          # the device-expanded key, downloaded

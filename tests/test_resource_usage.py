@@ -12,7 +12,7 @@ REPORT = os.path.join(ROOT, "tfhe.jl_amd", "build", "resource_usage.txt")
 # DIAG instantiations (rounding margin + in-kernel clock; run only under tfhe_set_option("measure_margin", 1)) that may
 # spill: the diagnostics add a live double and two 64-bit stamps to a kernel that is register-bound without them.
 DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 2>(MkBrArgs)", "void mk_blind_rotate_kernel_w2<4, true, 1>(MkBrArgs)",
-                  "void mk_blind_rotate_kernel_g2<4, 5, true, 2>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2>(MkGenArgs)",
+                  "void mk_blind_rotate_kernel_g2<4, 5, true, 2, true>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2, false>(MkGenArgs)",
                   "void blind_rotate_kernel_v3<1, 8, true, true, 4>(BrArgs)"}       # (l = 1: no shipped parameter set; 3 dwords)
 # Non-DIAG instantiations that keep ONE or TWO spilled dwords (an LDS address / a 64-bit key pointer reloaded once per CMUX
 # step of 3 000 - 30 000 instructions): the variants of these kernels that the compiler allocates without any scratch were
@@ -21,7 +21,7 @@ DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 2>(MkBrArgs)", "void 
 # bytes per lane, nothing more.
 SMALL_RESIDUE = {r"void blind_rotate_kernel_n2048<[34], false, [124]>\(Br2048Args\)": 12,
                  r"void blind_rotate_kernel_n2048<[234], true, [124]>\(Br2048Args\)": 24,
-                 r"void mk_blind_rotate_kernel_g2<(4, 5|8, 8), false, [24]>\(MkGenArgs\)": 24,
+                 r"void mk_blind_rotate_kernel_g2<(4, 5|8, 8), false, [24], (true|false)>\(MkGenArgs\)": 24,
                  # k = 2 with l = 1: no shipped parameter set; two LDS addresses reloaded once per polynomial
                  r"void blind_rotate_kernel_k2<1, (true|false), [17]>\(BrArgs\)": 16}
 

@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(64 * RW, 1) void mk_blind_rotate_kernel_general(MkG
 // sources unrolled inside it — exactly as in the 2-party kernel: a first version with run-time source lists and ONE copy of
 // the step needed its pass-A twiddles and the decomposed source in LDS to fit 256 registers and was 15 % SLOWER than the
 // any-party kernel (5.0 vs 4.35 ms per 96 steps x 1024 rotations: +40 % LDS reads per transform at two waves per SIMD).
-template <int NP, int L, int PARTY, int WV, bool MARGIN>
+template <int NP, int L, int PARTY, int WV, bool MARGIN, bool ACCL>
 __device__ __forceinline__ void g2_party_steps(const MkGenArgs &P, const int32_t *bara, int32_t *acc, cplx *xch_own, cplx *xch_oth,
                                                const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
 {
@@ -1148,13 +1148,19 @@ __device__ __forceinline__ void g2_party_steps(const MkGenArgs &P, const int32_t
             accumulate_poly<MARGIN>(lane, o_body, acc + NP * kImg, &worst);
         }
         // accumulator stores of this step visible to the other wave of the rotation; also ends the use of the LDS hand-off
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (ACCL: the accumulators are in LDS and the barrier alone orders them)
+        if constexpr (!ACCL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (!ACCL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 
-template <int NP, int L, bool MARGIN = false, int RW = 2>
+// ACCL (round 4): the accumulator images in LDS instead of global memory.  At 4 parties five images are 21.8 KB; with the
+// two transposition buffers a rotation takes 40 192 B, a pair of rotations + the twiddle table 81 408 B = 40 of the 2 KB
+// granules LDS is handed out in, so two such workgroups (or one of four rotations) fill a CU's 160 KB exactly and the
+// chip still holds 1024 rotations.  The step then needs no workgroup-scope fence and no trip to L2 for the accumulators.
+// (8 parties: nine images do not fit; the accumulators stay in global memory.)
+template <int NP, int L, bool MARGIN = false, int RW = 2, bool ACCL = false>
 __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_g2(MkGenArgs P)
 {
     unsigned long long dg_t0 = 0, dg_r0 = 0;
@@ -1168,7 +1174,9 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_g2(MkGenAr
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
     const bool live = w_raw < (size_t)P.R;                                       // a padding rotation repeats the last one, stores nothing
     const size_t w = live ? w_raw : (size_t)P.R - 1;
-    int32_t *acc = P.acc + w_raw * (size_t)(NP + 1) * kImg;                      // [NP+1][kImg], global memory
+    int32_t *acc;                                                                // [NP+1][kImg]
+    if constexpr (ACCL) acc = reinterpret_cast<int32_t *>(smem + ((size_t)RW * 2 * kXchElems + 64) * sizeof(cplx)) + (size_t)rot * (NP + 1) * kImg;
+    else acc = P.acc + w_raw * (size_t)(NP + 1) * kImg;                          // global memory
     const int32_t *bara = P.bara + w * ((size_t)NP * P.n + 1);
     const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
 
@@ -1182,16 +1190,16 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_g2(MkGenAr
         for (int s = wv; s < NP; s += 2) init_zero_poly(lane0, acc + s * kImg);
         if (wv == (NP & 1)) init_body_poly(lane0, load_uniform_i32(bara + (size_t)NP * P.n) & (2 * kN - 1), P.mu, acc + NP * kImg);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if constexpr (!ACCL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if constexpr (!ACCL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     wave_priority_begin(P.prio_steps);
     // party-major double loop (mk_internals.jl:475-476), one instantiation of the steps per (party, wave)
     if (wv == 0) {
-        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 0, MARGIN>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
+        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 0, MARGIN, ACCL>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
     } else {
-        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 1, MARGIN>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
+        static_for<0, NP>([&](auto pc) { g2_party_steps<NP, L, decltype(pc)::value, 1, MARGIN, ACCL>(P, bara, acc, xch_own, xch_oth, tw2_lds, tw1f, xormask, worst); });
     }
     if (!live) return;
     const int lane_e = lane_id_fresh();
@@ -1921,6 +1929,204 @@ __global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel
 
     if (!live) return;
     const int tid_e = ((wib & 1) << 6) + lane_id_fresh();      // thread within its rotation, rebuilt: threadIdx.x need not survive the loop
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_e == 0);
+    int32_t *ext = P.ext + w * (kN2 + 1);
+    for (int j = tid_e; j < kN2; j += 128) {
+        const int32_t v = acc_lds[kMir + j];
+        if (j == 0) ext[0] = v;
+        else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
+    }
+    if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
+}
+
+// ---- N = 2048, rotated words exchanged instead of computed twice (round 4) -------------------------------------------
+// blind_rotate_kernel_n2048 has BOTH waves of a rotation rotate and offset all 32 coefficient classes of both accumulator
+// polynomials (each needs every coefficient for its half of the frequencies): 2 x 406 of a wave's ~4950 instructions per
+// step, half of them scalar address arithmetic.  Here wave c rotates only polynomial c — the one it also updates, so an
+// accumulator polynomial is private to its wave and its update needs no barrier —, runs the L transforms of that
+// polynomial's digits, then parks the 32 rotated words (8 KB) in its transposition buffer, which is idle at that point;
+// after the barrier it takes the other wave's words from the other buffer and KEEPS that buffer for the remaining
+// transforms (the other wave does the same with this one's).  The hand-off of the inverse half-transforms swaps the
+// buffers back.  A wave's LDS operations execute in order, so a buffer a wave has just read is free for it to write;
+// the buffer it gave away it does not touch until the next exchange.  Still two barriers per step, one rotation per
+// wave instead of two, 16 more 16-byte LDS operations.  Same words as blind_rotate_kernel_n2048.
+template <int L, bool MARGIN = false, int RW = 2>
+__global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048Args P)
+{
+    constexpr int K1 = 2;
+#ifndef TFHE_N2048X_KPN
+#define TFHE_N2048X_KPN 2
+#endif
+    constexpr int KPN = TFHE_N2048X_KPN;      // co = 0 key values requested inside the transform
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wib = wave_in_block();
+    const int rot = wib >> 1;                                                     // rotation within the workgroup
+    constexpr size_t kRotBytes = K1 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx);
+    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][kImg2]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kImg2 * 4);   // [2][kXchElems]
+    cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
+    const bool wave1_0 = ((tid >> 6) & 1) != 0;
+    const int wv = wib & 1;                         // scalar copy: buffer and accumulator bases stay in scalar registers
+    int32_t *acc_own = acc_lds + wv * kImg2;                                       // wave c owns polynomial c
+    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
+    const bool live = w_raw < (size_t)P.R;
+    const size_t w = live ? w_raw : (size_t)P.R - 1;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1_0 ? 512 : 0) + q * 64 + lane0];
+    if (tid < 64) tw2_lds[tid] = P.tw2[tid];
+    {
+        const int barb = bara[P.n] & (2 * kN2 - 1);
+        int32_t v[32];
+#pragma unroll
+        for (int m = 0; m < 32; m++) {
+            const int idx = (lane0 + 64 * m + barb) & (2 * kN2 - 1);
+            v[m] = !wave1_0 ? 0 : (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+        store_cur<32>(lane0, v, acc_own);
+    }
+    __syncthreads();
+    STAMP_DECL;
+
+    int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
+    wave_priority_begin(P.prio_steps);
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        wave_priority_step(i, P.prio_steps);
+        const int a = a_next;
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);
+        // (lane and wave half rebuilt per step, the half as a per-lane value on purpose — see blind_rotate_kernel_n2048: what is
+        //  derived from them is then recomputed here instead of living, and being spilled, across the whole loop)
+        const int lane = lane_id_fresh();
+        int wvv;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(wvv) : "s"(wv));
+        const bool wave1 = wvv != 0;
+        const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + wv * kM;      // (scalar; the lane is added per transform)
+        cplx out[K1][8];
+#pragma unroll
+        for (int d = 0; d < K1; d++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
+        cplx *xch = xch_all + wv * kXchElems;                   // this wave's buffer at the start of a step
+        cplx *xch_other = xch_all + (1 - wv) * kXchElems;
+        int32_t temp[32];
+        rotate_poly<32>(lane, a, acc_own, P.g.offset, xormask, temp);
+        STAMP(0);
+        static_for<0, 2>([&](auto phc) {
+            constexpr int ph = decltype(phc)::value;
+            const int c = ph == 0 ? wv : 1 - wv;                // own polynomial first, then the other wave's
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+                cplx x[8];
+                static_for<0, 8>([&](auto rc) {
+                    constexpr int R = decltype(rc)::value;
+                    const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);
+                    const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
+                    x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
+                });
+                STAMP(1);
+                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM + lane;
+                cplx kv0[8];
+                fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch, [&]() {
+#pragma unroll
+                    for (int k2 = 0; k2 < KPN; k2++) kv0[k2] = kp[k2 * 64];
+                });
+#pragma unroll
+                for (int k2 = KPN; k2 < 8; k2++) kv0[k2] = kp[k2 * 64];
+                STAMP(2);
+                {
+                    cplx kv1[8];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) kv1[k2] = kp[(size_t)2 * kM + k2 * 64];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kv0[k2], out[0][k2]);
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], kv1[k2], out[1][k2]);
+                }
+                STAMP(3);
+            }
+            if (ph == 0) {
+                // park this wave's rotated words, take the other wave's, keep the buffer they came in
+                WAVE_LDS_FENCE();
+                int4 *mine = reinterpret_cast<int4 *>(xch);
+#pragma unroll
+                for (int j = 0; j < 8; j++) mine[j * 64 + lane] = make_int4(temp[4 * j], temp[4 * j + 1], temp[4 * j + 2], temp[4 * j + 3]);
+                __syncthreads();
+                const int4 *theirs = reinterpret_cast<const int4 *>(xch_other);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int4 v = theirs[j * 64 + lane];
+                    temp[4 * j] = v.x; temp[4 * j + 1] = v.y; temp[4 * j + 2] = v.z; temp[4 * j + 3] = v.w;
+                }
+                WAVE_LDS_FENCE();
+                cplx *t = xch; xch = xch_other; xch_other = t;
+                STAMP(10);
+            }
+        });
+        STAMP(4);
+        fft_inv_wave(lane, out[0], tw1f, tw2_lds, xch);
+        fft_inv_wave(lane, out[1], tw1f, tw2_lds, xch);
+        STAMP(5);
+        WAVE_LDS_FENCE();
+        if (wave1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[0][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[1][r];
+        }
+        __syncthreads();
+        STAMP(6);
+        cplx oth[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+        STAMP(7);
+        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) {
+            static_for<0, 8>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const cplx al = alpha[R], be = beta[R];
+                const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);
+                const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
+                const double bi = R == 0 ? -be.y : R == 4 ? -be.x : be.x * ei - be.y * er;
+                const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
+                const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
+                const double re0 = R == 0 ? pr : pr * c0r - pi * c0i, im0 = R == 0 ? pi : pr * c0i + pi * c0r;
+                const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
+                if (MARGIN) {
+                    const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
+                    worst = f0 > worst ? f0 : worst;
+                    worst = f1 > worst ? f1 : worst;
+                    worst = f2 > worst ? f2 : worst;
+                    worst = f3 > worst ? f3 : worst;
+                }
+                const int jlo = kMir + lane + 64 * R;
+                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
+                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
+                ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
+                const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
+                ap[jlo + 1536] = last;
+                if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);
+            });
+        };
+        if (wave1) finish(oth, out[1], acc_own);
+        else finish(out[0], oth, acc_own);
+        WAVE_LDS_FENCE();       // (no barrier: only this wave reads or writes acc_own, and the buffer just read is this wave's again)
+        STAMP(8);
+    }
+    STAMP_FLUSH(P.diag, wib);
+    __syncthreads();            // extraction reads both polynomials
+
+    if (!live) return;
+    const int tid_e = ((wib & 1) << 6) + lane_id_fresh();
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_e == 0);
     int32_t *ext = P.ext + w * (kN2 + 1);
     for (int j = tid_e; j < kN2; j += 128) {

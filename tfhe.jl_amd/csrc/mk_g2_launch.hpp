@@ -5,14 +5,20 @@
 #include <hip/hip_runtime.h>
 #include "kernels_blind_rotate.hpp"
 
-#define TFHE_G2_LAUNCHER(P, L, DG, RW) tfhe_launch_mk_g2_##P##_##L##_##DG##_##RW
-#define TFHE_G2_DECLARE(P, L, DG, RW) hipError_t TFHE_G2_LAUNCHER(P, L, DG, RW)(unsigned nblk, size_t lds_bytes, hipStream_t s, const MkGenArgs &ga)
-// (DG = 1: the DIAG instantiation, two rotations per workgroup only; RW: rotations per workgroup)
-TFHE_G2_DECLARE(4, 5, 1, 2); TFHE_G2_DECLARE(4, 5, 0, 2); TFHE_G2_DECLARE(4, 5, 0, 4);
-TFHE_G2_DECLARE(8, 8, 1, 2); TFHE_G2_DECLARE(8, 8, 0, 2); TFHE_G2_DECLARE(8, 8, 0, 4);
+#define TFHE_G2_LAUNCHER(P, L, DG, RW, AL) tfhe_launch_mk_g2_##P##_##L##_##DG##_##RW##_##AL
+#define TFHE_G2_DECLARE(P, L, DG, RW, AL) hipError_t TFHE_G2_LAUNCHER(P, L, DG, RW, AL)(unsigned nblk, size_t lds_bytes, hipStream_t s, const MkGenArgs &ga)
+// (DG = 1: the DIAG instantiation, two rotations per workgroup only; RW: rotations per workgroup; AL = 1: accumulators in LDS,
+//  4 parties only)
+TFHE_G2_DECLARE(4, 5, 1, 2, 1); TFHE_G2_DECLARE(4, 5, 0, 2, 1); TFHE_G2_DECLARE(4, 5, 0, 4, 1); TFHE_G2_DECLARE(4, 5, 0, 4, 0);
+TFHE_G2_DECLARE(8, 8, 1, 2, 0); TFHE_G2_DECLARE(8, 8, 0, 2, 0); TFHE_G2_DECLARE(8, 8, 0, 4, 0);
 
-inline hipError_t tfhe_launch_mk_g2(int parties, bool diag, int rw, unsigned nblk, size_t lds_bytes, hipStream_t s, const MkGenArgs &ga)
+// acc_lds is honoured at 4 parties only (rw = 4 without it is kept for A/B: option mkg_acc 1)
+inline hipError_t tfhe_launch_mk_g2(int parties, bool diag, int rw, bool acc_lds, unsigned nblk, size_t lds_bytes, hipStream_t s, const MkGenArgs &ga)
 {
-    if (parties == 4) return diag ? TFHE_G2_LAUNCHER(4, 5, 1, 2)(nblk, lds_bytes, s, ga) : rw == 4 ? TFHE_G2_LAUNCHER(4, 5, 0, 4)(nblk, lds_bytes, s, ga) : TFHE_G2_LAUNCHER(4, 5, 0, 2)(nblk, lds_bytes, s, ga);
-    return diag ? TFHE_G2_LAUNCHER(8, 8, 1, 2)(nblk, lds_bytes, s, ga) : rw == 4 ? TFHE_G2_LAUNCHER(8, 8, 0, 4)(nblk, lds_bytes, s, ga) : TFHE_G2_LAUNCHER(8, 8, 0, 2)(nblk, lds_bytes, s, ga);
+    if (parties == 4) {
+        if (diag) return TFHE_G2_LAUNCHER(4, 5, 1, 2, 1)(nblk, lds_bytes, s, ga);
+        if (!acc_lds) return TFHE_G2_LAUNCHER(4, 5, 0, 4, 0)(nblk, lds_bytes, s, ga);
+        return rw == 4 ? TFHE_G2_LAUNCHER(4, 5, 0, 4, 1)(nblk, lds_bytes, s, ga) : TFHE_G2_LAUNCHER(4, 5, 0, 2, 1)(nblk, lds_bytes, s, ga);
+    }
+    return diag ? TFHE_G2_LAUNCHER(8, 8, 1, 2, 0)(nblk, lds_bytes, s, ga) : rw == 4 ? TFHE_G2_LAUNCHER(8, 8, 0, 4, 0)(nblk, lds_bytes, s, ga) : TFHE_G2_LAUNCHER(8, 8, 0, 2, 0)(nblk, lds_bytes, s, ga);
 }

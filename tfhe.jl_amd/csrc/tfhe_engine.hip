@@ -85,6 +85,7 @@ struct tfhe_ctx {
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
+    int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels (launch_blind_rotate)
     int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
                                  //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
                                  //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
@@ -137,6 +138,7 @@ struct tfhe_ctx {
     uint32_t submits = 0;
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
+    int n2048_variant = 0;       // tfhe_set_option("n2048_variant", 0 | 1 | 2): 1 = blind_rotate_kernel_n2048 (both waves rotate both polynomials), 2 = blind_rotate_kernel_n2048x (rotated words exchanged); 0 = default (2)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
@@ -668,15 +670,17 @@ static void name_kernel(tfhe_ctx *c, const char *fmt, ...)
     c->last_kernel = buf;
 }
 
-static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
+// Blind rotation of rotations [first, first + R) of the batch (rows of the bara / ext workspaces): picks the kernel for a
+// batch of R rotations, launches it on `s` and names it.
+static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int32_t mu, hipStream_t s, const DiagArgs &diag)
 {
     BrArgs a;
-    int32_t rc = prepare_diag(c, R, s, a.diag);
-    if (rc) return rc;
+    a.diag = diag;
+    if (diag.margin_bits) { a.diag.margin_bits += first; a.diag.clk += 2 * first; }
     const bool dg = c->measure_margin;
-    a.bara = (const int32_t *)c->bara.p;
+    a.bara = (const int32_t *)c->bara.p + first * (size_t)(c->P.n + 1);
     a.bk = c->d_bk;
-    a.ext = (int32_t *)c->ext.p;
+    a.ext = (int32_t *)c->ext.p + first * ((size_t)c->P.k * c->P.N + 1);
     a.T = c->T;
     a.g = c->g;
     a.n = c->P.n;
@@ -692,11 +696,17 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         const int rw = c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);
         const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
-#define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
+        const bool xv = c->n2048_variant != 1;
+#define LAUNCH_2048_K(KERNEL, LL, DG, RWV)                                                                         \
         do {                                                                                                       \
             if (ldsb > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_n2048<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
-            hipLaunchKernelGGL((blind_rotate_kernel_n2048<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b); \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)KERNEL<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+            hipLaunchKernelGGL((KERNEL<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b);                    \
+        } while (0)
+#define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
+        do {                                                                                                       \
+            if (xv) LAUNCH_2048_K(blind_rotate_kernel_n2048x, LL, DG, RWV);                                        \
+            else LAUNCH_2048_K(blind_rotate_kernel_n2048, LL, DG, RWV);                                            \
         } while (0)
 #define LAUNCH_2048(LL)                                                                                            \
         do {                                                                                                       \
@@ -709,9 +719,10 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         } while (0)
         BR_CASES(LAUNCH_2048)
 #undef LAUNCH_2048_RW
+#undef LAUNCH_2048_K
 #undef LAUNCH_2048
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, "blind_rotate_kernel_n2048<%d>", L);
+        name_kernel(c, xv ? "blind_rotate_kernel_n2048x<%d,rw%d>" : "blind_rotate_kernel_n2048<%d,rw%d>", L, rw);
         (void)nblk;
         return TFHE_OK;
     }
@@ -725,6 +736,23 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
         // gets floor or ceil of R / (rounds x CUs) rotations, its other waves idle at the barriers (4096 rotations: rounds
         // of 6, 5 and 5 per CU).  Option k2_rw: 0 / 7 = this rule, 1 = single-rotation workgroups.
         const size_t cus = (size_t)c->cu_count;
+        if (!dg && c->k2_rw == 3) {
+            // experiment (round 4): groups of three in lockstep, two such workgroups per CU, dealt out by the dispatcher as slots
+            // free up — no rounds, six rotations per CU instead of seven
+            const size_t G = (R + 2) / 3;
+            a.grp_q = (int32_t)(R / G);
+            a.grp_big = (int32_t)(R % G);
+#define LAUNCH_K2(LL)                                                                                              \
+            do {                                                                                                   \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_k2<LL, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * ldsk))); \
+                hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false, 3>), dim3((unsigned)G), dim3(192), 3 * ldsk, s, a); \
+            } while (0)
+            BR_CASES(LAUNCH_K2)
+#undef LAUNCH_K2
+            HIP_TRY(c, hipGetLastError());
+            name_kernel(c, "blind_rotate_kernel_k2<%d,rw3>", L);
+            return TFHE_OK;
+        }
         const bool grouped = !dg && (c->k2_rw == 7 || c->k2_rw == 0);     // (never slower than single-rotation workgroups: 6.7 vs 6.9 ms at 64 rotations, 6.8 vs 7.6 at 512)
         if (grouped) {
             const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
@@ -832,6 +860,32 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
 #else
     return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: br_variant 1 (round-1 baseline kernel) is compiled only with -DTFHE_BUILD_BASELINE");
 #endif
+}
+
+// A batch whose size is not a multiple of what the chip holds pays for its last, partly filled round as for a full one
+// when every rotation is one wave: the one-wave kernel (blind_rotate_kernel_v3) has 2048 rotations resident at two waves per
+// SIMD, and a last round of r < 1024 leaves most SIMDs with one wave or none for the 4 - 5 ms a rotation takes.  So the
+// whole rounds go to the one-wave kernel and a last round of at most 1024 rotations to the kernels that put two or 4 l
+// waves on a rotation (blind_rotate_kernel_w2 / _h2: 1024 rotations in 3.3 ms instead of 5.0), one launch after the other on
+// the same stream — 3072 rotations: 5.7 + 3.3 ms instead of 9.7 (80-bit set).  Option br_split (default 1; 0: one launch).
+static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
+{
+    DiagArgs diag;
+    int32_t rc = prepare_diag(c, R, s, diag);
+    if (rc) return rc;
+    const size_t resident = 8 * (size_t)c->cu_count;          // rotations of blind_rotate_kernel_v3 on the chip
+    const bool one_wave_family = c->P.N == kN && c->P.k == 1 && (c->br_variant == 0 || c->br_variant == 4);
+    const size_t tail = R % resident;
+    if (c->br_split && one_wave_family && R > resident && tail > 0 && c->br_small >= 0 && tail <= (size_t)c->br_small) {
+        rc = launch_blind_rotate_part(c, 0, R - tail, mu, s, diag);
+        if (rc) return rc;
+        const std::string main_name = c->last_kernel;
+        rc = launch_blind_rotate_part(c, R - tail, tail, mu, s, diag);
+        if (rc) return rc;
+        c->last_kernel = main_name + " + " + c->last_kernel;
+        return TFHE_OK;
+    }
+    return launch_blind_rotate_part(c, 0, R, mu, s, diag);
 }
 
 static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const int32_t *e1, const int32_t *dst,
@@ -1179,7 +1233,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
+    t->br_tiny = c->br_tiny; t->br_split = c->br_split; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->n2048_variant = c->n2048_variant; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
     return TFHE_OK;
 }
 
@@ -1689,13 +1743,21 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         //  waiting for the slowest of 32 than it saves: 8 parties 424 vs 403 ms, 4 parties 94 vs 80 ms on one device.)
         // (up to two rotations per CU the pairs win: 4 parties 54 vs 69 ms at 512 rotations, 62 vs 79 ms for a single gate;
         //  8 parties 298 vs 374 ms at 256 — profiles/r03/r03j_*)
-        const int rw = dg ? 2 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : ((size_t)B <= 2 * (size_t)c->cu_count ? 2 : 4);
-        const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx);
+        // 4 parties: the five accumulator images (21.8 KB per rotation) fit LDS beside the transposition buffers at four
+        // rotations per CU — 81 408 B per pair of rotations = 40 LDS granules of 2 KB, two pairs or one group of four per CU —
+        // so the step needs neither the trip to L2 nor the workgroup-scope fence (round 4; option mkg_acc 1: global memory as at
+        // 8 parties, where nine images do not fit — kept for A/B with four rotations per workgroup only)
+        const bool acc_lds = NP == 4 && (c->mkg_acc != 1 || dg);
+        const int rw = dg ? 2 : (NP == 4 && !acc_lds) ? 4 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : ((size_t)B <= 2 * (size_t)c->cu_count ? 2 : 4);
+        const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx) + (acc_lds ? (size_t)rw * (NP + 1) * kImg * sizeof(int32_t) : 0);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
-        HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
-        ga.acc = (int32_t *)c->mk_acc.p;
-        HIP_TRY(c, tfhe_launch_mk_g2(NP, dg, rw, nblk, ldsg2, s, ga));
-        name_kernel(c, "mk_blind_rotate_kernel_g2<%d,%d>", NP, c->P.bs_l);
+        ga.acc = nullptr;
+        if (!acc_lds) {
+            HIP_TRY(c, c->mk_acc.reserve((size_t)nblk * rw * (NP + 1) * kImg * sizeof(int32_t)));
+            ga.acc = (int32_t *)c->mk_acc.p;
+        }
+        HIP_TRY(c, tfhe_launch_mk_g2(NP, dg, rw, acc_lds, nblk, ldsg2, s, ga));
+        name_kernel(c, acc_lds ? "mk_blind_rotate_kernel_g2<%d,%d,acc=lds>" : "mk_blind_rotate_kernel_g2<%d,%d>", NP, c->P.bs_l);
 #endif
     } else {
         MkGenArgs ga;
@@ -1974,6 +2036,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
+    if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_prio_pct")) {
         if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
         c->br_prio_pct = (int)value;
@@ -1992,7 +2055,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "k2_rw")) {
-        if (value != 0 && value != 1 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1 or 7");
+        if (value != 0 && value != 1 && value != 3 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1, 3 or 7");
         c->k2_rw = (int)value;
         return TFHE_OK;
     }
@@ -2002,6 +2065,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "n2048_variant")) {
+        if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_variant must be 0 (default), 1 (both waves rotate) or 2 (rotated words exchanged)");
+        c->n2048_variant = (int)value;
+        return TFHE_OK;
+    }
     if (!strcmp(name, "n2048_rw")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 0 (by batch size), 1, 2 or 4");
         c->n2048_rw = (int)value;

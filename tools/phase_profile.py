@@ -49,7 +49,7 @@ elif a.config == "4b":
     eng.set_option("measure_margin", 1)
     for _ in range(2): eng.gates(np.zeros(B, np.uint8), x, y)
     print(eng.last_kernel_name(), "BR ms", eng.last_timing_ms(0), "clock", eng.last_kernel_clock_mhz())
-    phases(eng, 630, ["rotate(x2)", "digits(x6)", "fwdFFT(x6)", "key+MAC(x6)", "barrier1", "invFFT(x2)", "xch-write+bar(x2)", "xch-read+bar(x2)", "recombine(x2)", "end-barrier"])
+    phases(eng, 630, ["rotate", "digits(x6)", "fwdFFT(x6)", "key+MAC(x6)", "(loop end)", "invFFT(x2)", "handoff-write+barrier", "handoff-read", "recombine", "end-barrier", "park+barrier+fetch (n2048x)"])
 else:
     p = tfhe.mktfhe_parameters_2party
     sks = [tfhe.SecretKey(rng, p) for _ in range(2)]
