@@ -2,7 +2,8 @@
 #
 # NOT EXECUTED IN THE BUILD IMAGE (no Julia there).  Anyone with Julia + TFHE.jl can close the "parity unpinned" gap:
 #
-#     julia --project=<env with TFHE.jl> julia/mint_fixtures.jl [outdir = tests/golden] [lwe_size = 16]
+#     julia --project=julia/TFHEMI355X julia/TFHEMI355X/scripts/mint_fixtures.jl [outdir = tests/golden] [lwe_size = 16]
+# (after `Pkg.develop(path="<TFHE.jl checkout>")` in that project, INTEGRATION.md §2; test/runtests.jl calls it too)
 #
 # writes  ref_gates80.tfhe   13 gate kinds x all input combinations, tfhe_parameters_80, seed 123 (test/runtests.jl:26-40)
 #         ref_gates128.tfhe  NAND / MUX truth tables, tfhe_parameters_128                     (test/runtests.jl:43-57)
@@ -13,7 +14,7 @@
 # `python -m pytest tests/test_golden.py` then checks the oracle (CPU) and the HIP engine (-m gpu) against the
 # reference's own output words, bit for bit (it picks up every tests/golden/ref_*.tfhe present).  Only the exported API computes anything (make_key_pair, encrypt, gate_*,
 # SharedKey, CloudKeyPart, MKCloudKey, mk_encrypt, mk_gate_nand: src/TFHE.jl:24-61); keys are flattened exactly as the
-# GPU shim does it (julia/TFHEMI355X.jl), so a fixture also pins the shim's layout.
+# GPU shim does it (julia/TFHEMI355X/src/TFHEMI355X.jl), so a fixture also pins the shim's layout.
 #
 # Container (tfhe.jl_amd/serialize.py): magic "TFHEMI355X\0" | version u32 | n_sections u32 | per section: name[16] |
 # dtype u32 (0 Int32, 1 Float64, 2 Complex{Float64}, 3 UInt8) | ndim u32 | shape u64[ndim] (C order) | raw data.
@@ -21,8 +22,7 @@
 using Random
 using TFHE
 
-include(joinpath(@__DIR__, "TFHEMI355X.jl"))
-using .TFHEMI355X: flatten, flatten_bootstrap_spectra, flatten_keyswitch_key, flatten_mk_spectra,
+using TFHEMI355X: flatten, flatten_bootstrap_spectra, flatten_keyswitch_key, flatten_mk_spectra,
                    NAND, OR, AND, XOR, XNOR, NOT, NOR, ANDNY, ANDYN, ORNY, ORYN, MUX, CONST0, CONST1
 
 dtype_code(::Type{Int32}) = UInt32(0)
@@ -115,7 +115,7 @@ with_lwe_size(p, n) = n == 0 ? p : TFHE.SchemeParameters(
     n, p.lwe_noise_stddev, p.tlwe_polynomial_degree, p.tlwe_mask_size, p.bs_decomp_length, p.bs_log2_base,
     p.bs_noise_stddev, p.ks_decomp_length, p.ks_log2_base, p.ks_noise_stddev, p.max_parties)
 
-outdir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden")
+outdir = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "..", "..", "tests", "golden")
 lwe_size = length(ARGS) >= 2 ? parse(Int, ARGS[2]) : 16
 mkpath(outdir)
 mint_single(joinpath(outdir, "ref_gates80.tfhe"), with_lwe_size(tfhe_parameters_80(), lwe_size),

@@ -2,13 +2,15 @@
 #
 # NOT EXECUTED IN THE BUILD IMAGE (no Julia there): kept literal so it can be reviewed by reading against
 # include/tfhe_mi355x.h; tests/test_julia_shim.py checks every ccall against the header, that no TFHE name is exported
-# without being imported from TFHE, and that every exported gate has its batched `broadcasted` method.
+# without being imported from TFHE, that every exported gate has its batched `broadcasted` method, and every size(...)
+# destructuring against the reference's comprehension order.  One command runs it where Julia exists (INTEGRATION.md §2):
+#     julia --project=julia/TFHEMI355X -e 'using Pkg; Pkg.develop(path="<TFHE.jl checkout>"); Pkg.test()'
 #
 # The module defines NO function named gate_*: it `import`s TFHE's functions (src/TFHE.jl:34-46,61) and adds methods
 # whose cloud-key argument is a GpuCloudKey / GpuMKCloudKey.  After
 #
 #     using TFHE, Random
-#     include("julia/TFHEMI355X.jl"); using .TFHEMI355X       # exports only GpuCloudKey, GpuMKCloudKey, GpuLweArray, ...
+#     using TFHEMI355X                                        # the package julia/TFHEMI355X (Project.toml: deps TFHE, Random); exports only GpuCloudKey, GpuMKCloudKey, GpuLweArray, ...
 #     rng = MersenneTwister(123)
 #     secret_key, cloud_key = make_key_pair(rng)
 #     gck = GpuCloudKey(cloud_key)                            # flattens + uploads the keys once (device 0)
@@ -34,12 +36,13 @@ using TFHE
 import TFHE: gate_nand, gate_or, gate_and, gate_xor, gate_xnor, gate_not, gate_constant,
              gate_nor, gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux, mk_gate_nand
 using TFHE: LweSample, LweParams, CloudKey, SecretKey, SchemeParameters, MKCloudKey, MKLweSample
-using Random: AbstractRNG
+using Random: AbstractRNG, RandomDevice
 import Base.Broadcast: broadcastable, broadcasted
 
 export GpuCloudKey, GpuMKCloudKey, GpuLweArray, gates_batch, gates_batch_async, PendingGates, upload, download
 
-const LIB = get(ENV, "TFHE_MI355X_LIB", joinpath(@__DIR__, "..", "tfhe.jl_amd", "lib", "libtfhe_mi355x.so"))
+# the shared library as this repository builds it (make -C tfhe.jl_amd/csrc), or wherever TFHE_MI355X_LIB points
+const LIB = get(ENV, "TFHE_MI355X_LIB", joinpath(@__DIR__, "..", "..", "..", "tfhe.jl_amd", "lib", "libtfhe_mi355x.so"))
 
 # include/tfhe_mi355x.h: struct tfhe_params
 struct TfheParams
@@ -156,13 +159,17 @@ end
 # generator such as RandomDevice()), the bootstrap and keyswitch keys never exist on the host.  The key material follows
 # the library's Philox streams, not MersenneTwister's.  Four of the seed words key the noise and are as secret as the
 # secret key (they regenerate the noise of every key row): the seed is not stored anywhere.
-function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing, wires::Integer=65536)
+function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0, devices=nothing, wires::Integer=65536,
+                     noise_seed=nothing)     # (tests only: four fixed words instead of RandomDevice())
     p = secret_key.params
     gck = GpuCloudKey(p, devices === nothing ? [device] : devices, wires)
     try
         lwe_bits = Int32.(secret_key.key.key)                                        # lwe.jl:11-17
         tlwe_bits = Int32.(rand(rng, Bool, p.tlwe_polynomial_degree, p.tlwe_mask_size))   # [N, k] = C-order [k][N]; tlwe.jl:15-20
-        seed = rand(rng, UInt32, 6)          # words 1-2 key the public masks, words 3-6 (128 bits) the noise: secret, discarded here
+        # words 1-2 key the public masks (from `rng`: reproducible), words 3-6 (128 bits) key the noise: secret, drawn from the
+        # operating system's generator whatever `rng` is (Philox then only expands that secret), discarded here
+        seed = vcat(rand(rng, UInt32, 2), noise_seed === nothing ? rand(RandomDevice(), UInt32, 4) : UInt32.(noise_seed))
+        length(seed) == 6 || error("GpuCloudKey: noise_seed must be four 32-bit words")
         GC.@preserve lwe_bits tlwe_bits seed check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
             gck.ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
@@ -357,12 +364,33 @@ function gates_batch_async(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=noth
         foreach(release_pinned, bufs)
         check(gck.ctx, rc)
     end
-    PendingGates(gck, ticket[], bufs, out, false)
+    t = PendingGates(gck, ticket[], bufs, out, false)
+    # a PendingGates that is dropped (or whose fetch is never reached) must not leak its page-locked buffers: wait for the
+    # batch, then free them (a finalizer may call into C; it must not allocate Julia objects, and this one does not)
+    finalizer(abandon!, t)
+    t
+end
+
+function abandon!(t::PendingGates)
+    t.done && return nothing
+    if t.key.ctx != C_NULL
+        ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)    # the DMA is over after this, error or not
+    end
+    foreach(release_pinned, t.buffers)
+    empty!(t.buffers)
+    t.done = true
+    nothing
 end
 
 function Base.fetch(t::PendingGates)
     t.done && error("PendingGates: already fetched")
     rc = ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)
+    if rc != 0
+        # a failed wait says nothing about the copies still in flight: wait on both streams before the buffers go back
+        for other in Int32(0):Int32(1)
+            ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, other)
+        end
+    end
     res = rc == 0 ? unflatten(copy(t.out), LweParams(t.key.params.lwe_size)) : nothing
     foreach(release_pinned, t.buffers)
     empty!(t.buffers)

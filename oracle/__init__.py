@@ -139,7 +139,7 @@ class Oracle:
 
     def load_bootstrap_spectra(self, spectra):
         """The key in the reference's stored form (complex128 [..., N/2], bootstrap.jl:12-14 / mk_internals.jl:442-461),
-        e.g. from a fixture minted by julia/mint_fixtures.jl: the FFT back-end then multiplies with exactly the
+        e.g. from a fixture minted by julia/TFHEMI355X/scripts/mint_fixtures.jl: the FFT back-end then multiplies with exactly the
         reference's spectra; the Int32 form (for the exact back-end) is their inverse transform (polynomials.jl:119-132)."""
         sp = np.ascontiguousarray(spectra, dtype=np.complex128)
         M = self.N // 2

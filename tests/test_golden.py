@@ -59,7 +59,7 @@ def test_gpu_reproduces_golden(tfhe, kat):
         e.close()
 
 
-# ---- fixtures minted by the REAL reference (julia/mint_fixtures.jl) ------------------------------------------------
+# ---- fixtures minted by the REAL reference (julia/TFHEMI355X/scripts/mint_fixtures.jl) ------------------------------------------------
 # Any tests/golden/ref_*.tfhe present is checked word for word against the oracle (CPU) and the HIP engine (GPU).
 # None can be minted in the build image (no Julia): the tests then skip, and a Python twin of the Julia writer — same
 # container, same section names, data from this repo's own keygen + oracle — keeps the reader / consumer code exercised.
@@ -124,7 +124,7 @@ def _reference_files():
 def test_oracle_reproduces_reference_fixtures(tfhe, orc):
     files = _reference_files()
     if not files:
-        pytest.skip("no tests/golden/ref_*.tfhe: mint them with julia/mint_fixtures.jl (needs Julia + TFHE.jl)")
+        pytest.skip("no tests/golden/ref_*.tfhe: mint them with julia/TFHEMI355X/scripts/mint_fixtures.jl (needs Julia + TFHE.jl)")
     from tfhe_jl_amd.serialize import read_sections
     for f in files:
         check_reference_fixture(read_sections(f), tfhe, orc, gpu=False)
@@ -134,14 +134,14 @@ def test_oracle_reproduces_reference_fixtures(tfhe, orc):
 def test_gpu_reproduces_reference_fixtures(tfhe, orc):
     files = _reference_files()
     if not files:
-        pytest.skip("no tests/golden/ref_*.tfhe: mint them with julia/mint_fixtures.jl (needs Julia + TFHE.jl)")
+        pytest.skip("no tests/golden/ref_*.tfhe: mint them with julia/TFHEMI355X/scripts/mint_fixtures.jl (needs Julia + TFHE.jl)")
     from tfhe_jl_amd.serialize import read_sections
     for f in files:
         check_reference_fixture(read_sections(f), tfhe, orc, gpu=True)
 
 
 def _mint_twin(tfhe, orc, path, multikey):
-    """Python twin of julia/mint_fixtures.jl (same container and section names), data from this repo's keygen + oracle."""
+    """Python twin of julia/TFHEMI355X/scripts/mint_fixtures.jl (same container and section names), data from this repo's keygen + oracle."""
     from tfhe_jl_amd.serialize import write_sections
     rng = np.random.default_rng(5)
     if multikey:

@@ -1,4 +1,4 @@
-"""Static checks of julia/*.jl (no Julia runtime exists in the build image): every `ccall` names a symbol the
+"""Static checks of the Julia package julia/TFHEMI355X (no Julia runtime exists in the build image): every `ccall` names a symbol the
 header declares, passes as many argument types and arguments as the C prototype has parameters, with pointer / integer /
 floating-point kinds that match; block keywords and brackets balance.  Not a substitute for running the shim — it catches
 the drift between `include/tfhe_mi355x.h` and the binding that would otherwise only show up on a machine with Julia."""
@@ -7,7 +7,8 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tfhe_mi355x.h")
-JULIA = [os.path.join(ROOT, "julia", f) for f in ("TFHEMI355X.jl", "mint_fixtures.jl")]
+PKG = os.path.join(ROOT, "julia", "TFHEMI355X")
+JULIA = [os.path.join(PKG, "src", "TFHEMI355X.jl"), os.path.join(PKG, "scripts", "mint_fixtures.jl"), os.path.join(PKG, "test", "runtests.jl")]
 
 
 def c_prototypes():
@@ -197,3 +198,75 @@ def test_every_gate_has_a_batched_broadcast_method():
         method = g in names or re.search(r"^" + g + r"\(\w+::" + key, src, flags=re.M)
         assert method, f"no {g}(::{key}, ...) method"
     assert re.search(r"broadcastable\(\w+::GpuCloudKey\)", src) and re.search(r"broadcastable\(\w+::GpuMKCloudKey\)", src)
+
+
+# ---- the package around the shim (round-3 verdict, missing #4): Project.toml, src/, test/runtests.jl ------------------
+def test_project_toml_declares_the_package():
+    import tomli
+    proj = tomli.load(open(os.path.join(PKG, "Project.toml"), "rb"))
+    assert proj["name"] == "TFHEMI355X" and os.path.exists(os.path.join(PKG, "src", proj["name"] + ".jl"))
+    assert re.fullmatch(r"[0-9a-f]{8}(-[0-9a-f]{4}){3}-[0-9a-f]{12}", proj["uuid"])
+    deps = proj["deps"]
+    assert set(deps) == {"TFHE", "Random"}, deps
+    assert deps["Random"] == "9a3f8284-a2c9-5f02-9a11-845980a1fd5c"
+    ref_uuid = "4bccc524-91da-45f4-9b13-e6dcce9f8221"                    # /root/reference/Project.toml:2
+    ref = "/root/reference/Project.toml"
+    if os.path.exists(ref):
+        assert tomli.load(open(ref, "rb"))["uuid"] == ref_uuid
+    assert deps["TFHE"] == ref_uuid
+    assert "Test" in proj["extras"] and proj["targets"]["test"] == ["Test"]
+    # every module the sources load is a dependency (or Base / a stdlib named in deps / extras)
+    for path in JULIA:
+        src = strip_julia(open(path).read())
+        for mod in re.findall(r"^\s*(?:using|import)\s+([A-Z]\w*)", src, flags=re.M):
+            assert mod in deps or mod in proj["extras"] or mod in ("Base", "TFHEMI355X"), f"{os.path.basename(path)} loads {mod}, which Project.toml does not list"
+
+
+def test_runtests_drives_the_references_cases_through_the_gpu_keys():
+    src = strip_julia(open(JULIA[2]).read())
+    for need in (r"GpuCloudKey\(cloud_key\)", r"GpuMKCloudKey\(cloud_key\)", r"tfhe_parameters_128\(\)", r"mktfhe_parameters_2party",
+                 r"gate_xor\.\(gck, c1, c2\)", r"gate_xor\.\(cloud_key, c1, c2\)", r"mk_gate_nand\(mck,", r"mk_gate_nand\(cloud_key,",
+                 r"MersenneTwister\(123\)"):
+        assert re.search(need, src), need
+    assert '"scripts", "mint_fixtures.jl"' in open(JULIA[2]).read()         # (string literals are blanked in `src`)
+    names = re.findall(r'^\s*\(\s*"\s*"\s*,\s*(gate_\w+)', src, flags=re.M)          # the 12-gate table (string literals are blanked)
+    assert sorted(names) == sorted(g for g in GATES if g not in ("gate_constant", "mk_gate_nand")), names
+
+
+def _comprehension_vars(path, anchor):
+    """Loop variables, in order, of the first `for a in ..., b in ...` that follows `anchor` in a reference source file."""
+    src = open(path).read()
+    i = src.index(anchor)
+    m = re.search(r"\bfor\s+([^\n]*)", src[i:])
+    return re.findall(r"(\w+)\s+in\s", m.group(1))
+
+
+def test_size_destructurings_follow_the_references_array_orders():
+    """A Julia array built by a comprehension `[f(..) for a in A, b in B, c in C]` has size (|A|, |B|, |C|) and is indexed
+    [a, b, c]: every size(...) the shim destructures, and every index expression it applies to a reference array, must use
+    the order the reference's comprehension fixes (keyswitch.jl:35-38, mk_internals.jl:453-455, :6-18)."""
+    src = strip_julia(open(JULIA[0]).read())
+    ks_order, mk_order = ["h", "j", "i"], ["j", "i"]
+    if os.path.exists("/root/reference/src/keyswitch.jl"):
+        assert _comprehension_vars("/root/reference/src/keyswitch.jl", "ks = [") == ks_order
+        assert _comprehension_vars("/root/reference/src/mk_internals.jl", "samples = [\n            mk_tgsw_expand") == mk_order
+        assert "(n, parties)" in open("/root/reference/src/mk_internals.jl").read()
+    # KeyswitchKey.key: size = (base - 1, t, kN), indexed [h, j, i]
+    m = re.search(r"(\w+), (\w+), (\w+) = size\(ks\.key\)", src)
+    assert m, "flatten_keyswitch_key no longer destructures size(ks.key)"
+    d_h, d_j, d_i = m.groups()
+    loop = re.search(r"for (\w+) in 1:(\w+), (\w+) in 1:(\w+), (\w+) in 1:(\w+)\s*\n\s*s = ks\.key\[(\w+), (\w+), (\w+)\]", src)
+    assert loop, "the loop over ks.key changed shape"
+    ranges = {loop.group(1): loop.group(2), loop.group(3): loop.group(4), loop.group(5): loop.group(6)}
+    idx = [loop.group(7), loop.group(8), loop.group(9)]
+    assert [ranges[v] for v in idx] == [d_h, d_j, d_i], "index variables are not bounded by the matching size() components"
+    assert idx == ks_order, f"ks.key is indexed {idx}, the reference builds it {ks_order}"
+    # the flat copy is filled [.., h, j, i] in column-major = C order [i][j][h][n+1]
+    assert re.search(r"flat\[1:n, h, j, i\]", src) and re.search(r"undef, n \+ 1, " + d_h + ", " + d_j + ", " + d_i, src)
+    # MKBootstrapKey.key: (n, parties), indexed [j, i]
+    mk = re.search(r"for (\w+) in 1:parties, (\w+) in 1:n\s*\n\s*s = bk\.key\[(\w+), (\w+)\]", src)
+    assert mk and [mk.group(3), mk.group(4)] == [mk.group(2), mk.group(1)] == mk_order
+    # MKLweSample.a: (n, parties)
+    assert re.search(r"n, P = size\(xs\[1\]\.a\)", src) and re.search(r"reshape\(out\[1:n\*P, g\], n, P\)", src)
+    # BootstrapKey: key[i].samples[p, j].a[c] (tgsw.jl:35-42 samples is l x (k + 1))
+    assert re.search(r"bk\.key\[i\]\.samples\[pp, j\]\.a\[c\]\.coeffs", src)

@@ -85,7 +85,7 @@ struct tfhe_ctx {
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
-    int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels (launch_blind_rotate)
+    int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels in a second launch (launch_blind_rotate)
     int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
                                  //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
                                  //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
@@ -736,23 +736,9 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         // gets floor or ceil of R / (rounds x CUs) rotations, its other waves idle at the barriers (4096 rotations: rounds
         // of 6, 5 and 5 per CU).  Option k2_rw: 0 / 7 = this rule, 1 = single-rotation workgroups.
         const size_t cus = (size_t)c->cu_count;
-        if (!dg && c->k2_rw == 3) {
-            // experiment (round 4): groups of three in lockstep, two such workgroups per CU, dealt out by the dispatcher as slots
-            // free up — no rounds, six rotations per CU instead of seven
-            const size_t G = (R + 2) / 3;
-            a.grp_q = (int32_t)(R / G);
-            a.grp_big = (int32_t)(R % G);
-#define LAUNCH_K2(LL)                                                                                              \
-            do {                                                                                                   \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_k2<LL, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * ldsk))); \
-                hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false, 3>), dim3((unsigned)G), dim3(192), 3 * ldsk, s, a); \
-            } while (0)
-            BR_CASES(LAUNCH_K2)
-#undef LAUNCH_K2
-            HIP_TRY(c, hipGetLastError());
-            name_kernel(c, "blind_rotate_kernel_k2<%d,rw3>", L);
-            return TFHE_OK;
-        }
+        // (Round 4, measured dead end: groups of THREE in lockstep, two such workgroups per CU, handed out by the dispatcher as
+        //  slots free up — no rounds, six rotations per CU: 1792 rotations 15.8 vs 11.4 ms, 4096: 30.8 vs 29.9, 7168: 49.9 vs 43.5,
+        //  16384: 105.5 vs 100.1; gpurun_out/r04b_k2.jsonl -> profiles/r04/)
         const bool grouped = !dg && (c->k2_rw == 7 || c->k2_rw == 0);     // (never slower than single-rotation workgroups: 6.7 vs 6.9 ms at 64 rotations, 6.8 vs 7.6 at 512)
         if (grouped) {
             const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
@@ -864,25 +850,36 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 
 // A batch whose size is not a multiple of what the chip holds pays for its last, partly filled round as for a full one
 // when every rotation is one wave: the one-wave kernel (blind_rotate_kernel_v3) has 2048 rotations resident at two waves per
-// SIMD, and a last round of r < 1024 leaves most SIMDs with one wave or none for the 4 - 5 ms a rotation takes.  So the
-// whole rounds go to the one-wave kernel and a last round of at most 1024 rotations to the kernels that put two or 4 l
-// waves on a rotation (blind_rotate_kernel_w2 / _h2: 1024 rotations in 3.3 ms instead of 5.0), one launch after the other on
-// the same stream — 3072 rotations: 5.7 + 3.3 ms instead of 9.7 (80-bit set).  Option br_split (default 1; 0: one launch).
+// SIMD, and a last round of r <= 1024 leaves most SIMDs with one wave or none for the 4 - 5 ms a rotation takes.  So the
+// whole rounds go to the one-wave kernel and a last round of at most br_small (1024) rotations to the kernels that put two
+// or 4 l waves on a rotation (blind_rotate_kernel_w2 / _h2), one launch after the other on the same stream.  Same device,
+// interleaved (profiles/r04/r04c_split80.jsonl, 80-bit set; the parts alone: 2048 rotations 5.87 ms, 1024: 3.33, 512: 2.27):
+//     2560 rotations 8.79 vs 9.84 ms in one launch, 3072: 9.53 vs 9.70, 5000: 15.29 vs 15.56, 6400: 19.58 vs 21.18;
+//     128-bit set 3072: 15.43 vs 15.92, 5000: 24.57 vs 25.26.
+// Likewise a batch just above br_small: the first br_small rotations on the two-wave kernel, up to one rotation per CU more
+// on the 4 l-wave kernel (1100 rotations: 3.3 + 1.8 ms instead of 5.4 on the one-wave kernel).
+// (Measured dead end: the tail on a second stream, launched first so that the whole rounds move into the slots it frees —
+//  3072 rotations 9.39 ms, but 2560: 10.7 and 5000: 15.8: whichever kernel the dispatcher favours starves the other.)
+// Option br_split (default 1; 0: always one launch).
 static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
 {
     DiagArgs diag;
     int32_t rc = prepare_diag(c, R, s, diag);
     if (rc) return rc;
     const size_t resident = 8 * (size_t)c->cu_count;          // rotations of blind_rotate_kernel_v3 on the chip
-    const bool one_wave_family = c->P.N == kN && c->P.k == 1 && (c->br_variant == 0 || c->br_variant == 4);
-    const size_t tail = R % resident;
-    if (c->br_split && one_wave_family && R > resident && tail > 0 && c->br_small >= 0 && tail <= (size_t)c->br_small) {
-        rc = launch_blind_rotate_part(c, 0, R - tail, mu, s, diag);
+    const bool family = c->P.N == kN && c->P.k == 1 && (c->br_variant == 0 || c->br_variant == 4) && c->br_split && c->br_small > 0;
+    const size_t small = family ? (size_t)c->br_small : 0;
+    const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
+    size_t head = 0;                                          // rotations of the first launch; 0: one launch
+    if (family && R > resident && R % resident > 0 && R % resident <= small) head = R - R % resident;
+    else if (family && R > small && small <= resident / 2 && tiny > 0 && R - small <= (size_t)tiny && c->P.bs_l <= 3) head = small;
+    if (head) {
+        rc = launch_blind_rotate_part(c, 0, head, mu, s, diag);
         if (rc) return rc;
-        const std::string main_name = c->last_kernel;
-        rc = launch_blind_rotate_part(c, R - tail, tail, mu, s, diag);
+        const std::string head_name = c->last_kernel;
+        rc = launch_blind_rotate_part(c, head, R - head, mu, s, diag);
         if (rc) return rc;
-        c->last_kernel = main_name + " + " + c->last_kernel;
+        c->last_kernel = head_name + " + " + c->last_kernel;
         return TFHE_OK;
     }
     return launch_blind_rotate_part(c, 0, R, mu, s, diag);
@@ -2055,7 +2052,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "k2_rw")) {
-        if (value != 0 && value != 1 && value != 3 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1, 3 or 7");
+        if (value != 0 && value != 1 && value != 7) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_rw must be 0 (by batch size), 1 or 7");
         c->k2_rw = (int)value;
         return TFHE_OK;
     }

@@ -2,7 +2,7 @@
 
 The reference has no (de)serialisation at all (keys live only as Julia object graphs); this is the
 engine's own versioned container so that keys minted elsewhere — e.g. by real TFHE.jl through
-julia/TFHEMI355X.jl's flattening — can be replayed on a GPU box.  Layout (little endian):
+julia/TFHEMI355X/src/TFHEMI355X.jl's flattening — can be replayed on a GPU box.  Layout (little endian):
 
     magic  b"TFHEMI355X\\0"  (11 bytes) | version u32 | n_sections u32
     per section:  name (16 bytes, NUL padded) | dtype code u32 (0 = int32, 1 = float64, 2 = complex128, 3 = uint8)

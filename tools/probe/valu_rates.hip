@@ -1,5 +1,5 @@
 // Issue cost of the vector instructions the blind-rotate kernels are made of, on gfx950: cycles per wave-instruction for
-// ONE wave on a SIMD and for TWO waves sharing it (s_memtime around an unrolled block of independent instructions).
+// ONE wave on a SIMD and for two, three and four waves sharing it (s_memtime around an unrolled block of independent instructions).
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rates tools/probe/valu_rates.hip && /tmp/valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,7 +19,7 @@
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                            \
     T s = 0;                                                                                               \
     for (int i = 0; i < REP; i++) s += r[i];                                                               \
-    if (threadIdx.x == 0) out[blockIdx.x * 2 + (threadIdx.x >> 6)] = t1 - t0;                              \
+    if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;                              \
     if (s == (T)12345) sink[0] = (double)s;
 
 __global__ void k_add_f64(unsigned long long *out, double *sink, double a)
@@ -75,14 +75,18 @@ __global__ void k_pk_fma_f32(unsigned long long *out, double *sink, double a)
 template <typename K>
 static void run(const char *name, K kernel)
 {
-    unsigned long long *out, h[4];
+    unsigned long long *out, h[16];
     double *sink;
-    (void)hipMalloc(&out, 64); (void)hipMalloc(&sink, 16);
-    for (int waves = 1; waves <= 2; waves++) {
+    (void)hipMalloc(&out, 128); (void)hipMalloc(&sink, 16);
+    for (int waves = 1; waves <= 4; waves++) {
         for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(kernel, dim3(1), dim3(64 * 4 * waves), 0, 0, out, sink, 1.0000001);
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
-        printf("%-14s %d wave(s) per SIMD: %6.2f cycles per wave-instruction (per wave)\n", name, waves, (double)h[0] / (REP * ITERS));
+        (void)hipMemcpy(h, out, 128, hipMemcpyDeviceToHost);
+        unsigned long long lo = h[0], hi = h[0];
+        for (int w = 1; w < 4 * waves; w++) { lo = h[w] < lo ? h[w] : lo; hi = h[w] > hi ? h[w] : hi; }
+        // the SIMD's arbiter favours its oldest wave: the fastest wave shows what one wave can issue, the slowest what the pipe sustains
+        printf("%-14s %d wave(s) per SIMD: fastest wave %6.2f, slowest %6.2f cycles per wave-instruction -> %5.2f cycles per instruction on the SIMD\n",
+               name, waves, (double)lo / (REP * ITERS), (double)hi / (REP * ITERS), (double)hi / (REP * ITERS) / waves);
     }
     (void)hipFree(out); (void)hipFree(sink);
 }
