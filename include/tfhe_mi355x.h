@@ -27,6 +27,14 @@
  * batch call out over its devices on library-owned threads and streams (keys replicated at load,
  * contiguous rotation-balanced shards, results written straight into the caller's buffer).  Calls on
  * one context must not overlap (one caller at a time); distinct contexts are independent.
+ *
+ * Parameter sets.  The reference validates nothing (SchemeParameters is a positional struct, tlwe_mask_size a free
+ * keyword: api.jl:4-21,30,55).  Single key: tfhe_ctx_create accepts N = 1024 or 2048, tlwe_mask_size k <= 4, any
+ * bs_decomp_length l with l * bs_log2_base <= 32, lwe_size <= 1023, any keyswitch base / length with t * gamma <= 31.
+ * Tuned kernels exist for k <= 2 with l <= 4 at N = 1024 and for k = 1 with l <= 4 at N = 2048 (every shipped set and
+ * BASELINE config 4b); everything else runs on blind_rotate_kernel_general — same words, several times slower.
+ * Multi-key: N = 1024, k = 1 (as the reference, mk_internals.jl:89-91), 2..8 parties, l <= 8.  Outside that
+ * (N other than 1024 / 2048, k > 4, multi-key at N = 2048): TFHE_ERR_UNSUPPORTED.
  */
 #ifndef TFHE_MI355X_H
 #define TFHE_MI355X_H

@@ -29,8 +29,9 @@
 #endif
 
 #define ORC_MAX_N 4096
-#define ORC_MAX_L 8
-#define ORC_MAX_K 2
+#define ORC_MAX_L 32        /* single key: any l with l * beta <= 32 */
+#define ORC_MAX_L_MK 8      /* multi-key (thread-local digit buffers are sized by it) */
+#define ORC_MAX_K 4
 #define ORC_MAX_PARTIES 8
 
 typedef struct {
@@ -565,7 +566,7 @@ static void mk_extern_mul_add(const orc_params *P, int Pn, int party, const int3
 {
     const int N = P->N, M = N / 2, l = P->l;
     /* decompose all Pn masks and b: dec[(i)][p][N], i = 0..Pn (Pn == b)      :355-356 */
-    static _Thread_local int32_t dec[(ORC_MAX_PARTIES + 1) * ORC_MAX_L * ORC_MAX_N];
+    static _Thread_local int32_t dec[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * ORC_MAX_N];
     for (int i = 0; i <= Pn; i++) orc_decompose(temp + (size_t)i * N, N, l, P->log2Bg, dec + (size_t)i * l * N);
     const size_t X0 = 0, Y0 = (size_t)l * Pn, C0 = (size_t)2 * l * Pn, C1 = C0 + l;
 
@@ -593,8 +594,8 @@ static void mk_extern_mul_add(const orc_params *P, int Pn, int party, const int3
     }
     /* mode 0: the reference inverse-transforms every product separately and sums in Int32
      * (:359-366 explains why); restated literally. */
-    static _Thread_local double dre[(ORC_MAX_PARTIES + 1) * ORC_MAX_L * (ORC_MAX_N / 2)];
-    static _Thread_local double dim[(ORC_MAX_PARTIES + 1) * ORC_MAX_L * (ORC_MAX_N / 2)];
+    static _Thread_local double dre[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * (ORC_MAX_N / 2)];
+    static _Thread_local double dim[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * (ORC_MAX_N / 2)];
     for (int i = 0; i <= Pn; i++)
         for (int p = 0; p < l; p++)                                                         /* :368-369 */
             orc_forward_transform(dec + ((size_t)i * l + p) * N, N, dre + ((size_t)i * l + p) * M, dim + ((size_t)i * l + p) * M);
@@ -637,7 +638,7 @@ int orc_mk_bootstrap_wo_keyswitch(const orc_params *P, int32_t Pn, const double 
                                   int32_t *out, double *margin)
 {
     const int N = P->N, n = P->n, l = P->l;
-    if (Pn > ORC_MAX_PARTIES || N > ORC_MAX_N || l > ORC_MAX_L) return -1;
+    if (Pn > ORC_MAX_PARTIES || N > ORC_MAX_N || l > ORC_MAX_L_MK) return -1;
     if (mode == 0 && !get_plan(N)) return -1;
     const int log2_2N = ilog2(2 * N);
     static _Thread_local int32_t acc[(ORC_MAX_PARTIES + 1) * ORC_MAX_N], temp[(ORC_MAX_PARTIES + 1) * ORC_MAX_N];

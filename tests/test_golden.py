@@ -45,15 +45,16 @@ def test_gpu_reproduces_golden(tfhe, kat):
         e.set_option("ks_variant", 3)
     assert ei.value.code == 5
     e.close()
-    # every kernel variant gives the same words (br_small = -1: one wave per rotation even for small batches;
-    # default: the two-waves-per-rotation kernel takes batches this small)
-    for bv, kv, small in ((2, 1, -1), (2, 3, -1), (3, 3, -1), (2, 4, -1), (0, 4, -1), (0, 4, 512)):
+    # every kernel family gives the same words (br_small = -1 / br_tiny = -1: one wave per rotation even for small batches;
+    # default: the multi-wave kernels take batches this small; br_general: the any-parameter kernel)
+    for bg, kv, small in ((0, 1, -1), (0, 3, -1), (1, 3, -1), (1, 4, -1), (0, 4, -1), (0, 4, 512)):
         e = tfhe.Engine(params, 0)
         e.set_option("ks_variant", kv)               # before the key load: only that family's layout is built
         e.load_bootstrap_key(kat["bootstrap_key"])
         e.load_keyswitch_key(kat["keyswitch_key"])
-        e.set_option("br_variant", bv)
+        e.set_option("br_general", bg)
         e.set_option("br_small", small)
+        e.set_option("br_tiny", -1 if small < 0 else -2)
         assert np.array_equal(e.gates(kat["ops"], kat["in0"], kat["in1"], kat["in2"]), kat["out"])
         assert np.array_equal(e.keyswitch(kat["ext"]), kat["ks_out"])
         e.close()

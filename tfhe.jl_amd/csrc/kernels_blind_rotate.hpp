@@ -138,114 +138,6 @@ __device__ __forceinline__ void wave_priority_step(int step, int prio_steps)
     else if (step == prio_steps) __builtin_amdgcn_s_setprio(0);
 }
 
-#ifdef TFHE_BUILD_BASELINE      // round-1 baseline (one wave per rotation, barriers, twiddles from global memory): A/B builds only
-template <int K1>
-__device__ __forceinline__ void store_acc(int lane, const int32_t (&acc)[16], int32_t *acc_lds)
-{
-#pragma unroll
-    for (int m = 0; m < 16; m++) acc_lds[lane + 64 * m] = acc[m];
-}
-
-// One wave = one blind rotation + extraction.
-template <int L, int K1>
-__global__ __launch_bounds__(64) void blind_rotate_kernel(BrArgs P)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);            // [K1][N]
-    cplx *xch = reinterpret_cast<cplx *>(smem + K1 * kN * 4);        // [kXchElems]
-    const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
-    const int32_t *bara = P.bara + w * (P.n + 1);
-
-    // accum = (0, ..., 0, X^{-barb} * (mu, ..., mu))     bootstrap.jl:54-56,78 ; tlwe.jl:77-81
-    int32_t acc[K1][16];
-    {
-        const int barb = bara[P.n] & (2 * kN - 1);
-#pragma unroll
-        for (int c = 0; c < K1 - 1; c++)
-#pragma unroll
-            for (int m = 0; m < 16; m++) acc[c][m] = 0;
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN - 1);
-            acc[K1 - 1][m] = (idx & kN) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-#pragma unroll
-        for (int c = 0; c < K1; c++) store_acc<K1>(lane, acc[c], acc_lds + c * kN);
-    }
-    __syncthreads();
-
-    for (int i = 0; i < P.n; i++) {                                   // bootstrap.jl:33
-        const int a = bara[i] & (2 * kN - 1);
-        if (a == 0) continue;                                         // bootstrap.jl:34
-        const cplx *bki = P.bk + (size_t)i * (L * K1 * K1 * kM);
-        cplx out[K1][8];
-#pragma unroll
-        for (int c = 0; c < K1; c++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) out[c][q] = mk(0.0, 0.0);
-
-#pragma unroll
-        for (int c = 0; c < K1; c++) {
-            int32_t temp[16];
-            rotate_sub(lane, a, acc_lds + c * kN, acc[c], P.g.offset, temp);   // bootstrap.jl:21
-#pragma unroll
-            for (int p = 1; p <= L; p++) {
-                cplx x[8];
-                load_digits(lane, temp, p, P.g, P.T, x);                      // tgsw.jl:126-127
-                fwd_pass_a(lane, x, P.T);
-                x1_store_a(lane, x, xch);
-                __syncthreads();
-                x1_load_b(lane, x, xch);
-                __syncthreads();
-                fwd_pass_b(lane, x, P.T);
-                x2_store(lane, x, xch);
-                __syncthreads();
-                x2_load(lane, x, xch);
-                __syncthreads();
-                fwd_pass_c(x);
-                // out[co] += D[p, c] .* BK_i[p, c].a[co]                      tgsw.jl:128
-                const cplx *kp = bki + (size_t)((p - 1) * K1 + c) * K1 * kM + lane;
-#pragma unroll
-                for (int co = 0; co < K1; co++)
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kp[(co * 8 + k2) * 64], out[co][k2]);
-            }
-        }
-#pragma unroll
-        for (int co = 0; co < K1; co++) {                                      // polynomials.jl:119-132
-            inv_pass_c(out[co]);
-            x2_store(lane, out[co], xch);
-            __syncthreads();
-            x2_load(lane, out[co], xch);
-            __syncthreads();
-            inv_pass_b(lane, out[co], P.T);
-            x1_store_b(lane, out[co], xch);
-            __syncthreads();
-            x1_load_a(lane, out[co], xch);
-            __syncthreads();
-            inv_pass_a(lane, out[co], P.T);
-            untwist_add(lane, out[co], P.T, acc[co]);                          // bootstrap.jl:22
-            store_acc<K1>(lane, acc[co], acc_lds + co * kN);
-        }
-        __syncthreads();
-    }
-
-    // tlwe_extract_sample (tlwe.jl:55-59): a'[0] = p[0], a'[m] = -p[N-m]; b' = body[0]
-    int32_t *ext = P.ext + w * ((K1 - 1) * kN + 1);
-#pragma unroll
-    for (int c = 0; c < K1 - 1; c++)
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            const int j = lane + 64 * m;
-            if (j == 0) ext[c * kN] = acc[c][m];
-            else ext[c * kN + kN - j] = (int32_t)(0u - (uint32_t)acc[c][m]);
-        }
-    if (lane == 0) ext[(K1 - 1) * kN] = acc[K1 - 1][0];
-}
-
-#endif  // TFHE_BUILD_BASELINE
-
 // Wave-private LDS hand-off: LDS instructions of one wave execute in issue order, so a compiler-level
 // fence is all a single-wave workgroup needs between a ds_write and the ds_read of another lane's data.
 #define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
@@ -784,7 +676,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
                 cplx x[8];
                 load_digits2(temp, p + 1, beta, x);
                 cplx kbo[8];
-                // (the first values of the second poly are requested inside the transform, where x[] is dead: see blind_rotate_kernel_n2048)
+                // (the first values of the second poly are requested inside the transform, where x[] is dead: see blind_rotate_kernel_n2048x)
                 fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch_own, [&]() {
 #pragma unroll
                     for (int k2 = 0; k2 < MKPN; k2++) kbo[k2] = k_body[k2 * 64];
@@ -1704,7 +1596,8 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_k2(BrArgs P)
 // 8 KB hand-off each way, two barriers per step).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
 //   wave 0 pass-A input  x_r = e^{-i pi r/32}  (u + kappa u'),   lane factor w^t             in tw1f
 //   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
-// Every wave rotates/decomposes all four coefficient classes it needs (t+64m, m < 32) itself.
+// Every wave decomposes all four coefficient classes it needs (t+64m, m < 32) itself; the rotation of a polynomial is done
+// by one wave and handed to the other (blind_rotate_kernel_n2048x below).
 constexpr int kN2 = 2048;
 
 __host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
@@ -1752,204 +1645,59 @@ __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx 
     fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
 }
 
-// RW rotations per workgroup (2 waves each) advance in lockstep (the barriers are workgroup-wide): the transformed
-// key of N = 2048 sets (124 MB at n = 630, l = 3) does not stay in the 4 MB L2 of an XCD once workgroups drift apart,
-// and rotations that read the same key values at the same time share one trip to the Infinity Cache.
-template <int L, bool MARGIN = false, int RW = 2>
-__global__ __launch_bounds__(128 * RW, RW == 4 ? 2 : 2) void blind_rotate_kernel_n2048(Br2048Args P)
+// Recombination of the two inverse half-transforms of one N = 2048 output polynomial (alpha: even frequencies' half, beta:
+// odd), untwist, round, add into the polynomial image `ap` (mirror included): the inverse of the radix-2 split above.
+template <bool MARGIN>
+__device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap, double &worst)
 {
-    constexpr int K1 = 2;
-#ifndef TFHE_N2048_KPN
-#define TFHE_N2048_KPN 2      // measured on one device, 4096 rotations of config 4b: 0: 54.2 ms, 1: 49.8, 2: 48.0, 3: 49.9, 4: 49.3-50.1, 6: 48.6-49.2, 8: 49.4-50.4
-#endif
-    constexpr int KPN = TFHE_N2048_KPN;      // co = 0 key values requested inside the transform (0: all after it)
-    constexpr bool KPRE = KPN > 0;
-    unsigned long long dg_t0 = 0, dg_r0 = 0;
-    diag_begin<MARGIN>(dg_t0, dg_r0);
-    double worst = 0.0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wib = wave_in_block();
-    const int rot = wib >> 1;                                                     // rotation within the workgroup
-    constexpr size_t kRotBytes = K1 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx);
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][kImg2]
-    cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kImg2 * 4);   // [2 waves][kXchElems]
-    cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
-    // (which half a wave takes is deliberately NOT derived from the scalar wave index: measured on one device, config 4b,
-    //  44.6 ms this way against 46.5 ms with a scalar `wave1` and 45.0 ms with nothing scalar — the per-wave constants of
-    //  the radix-2 split are then selected per lane instead of by branches)
-    const bool wave1 = ((tid >> 6) & 1) != 0;
-    cplx *xch = xch_all + (wave1 ? kXchElems : 0);
-    cplx *xch_other = xch_all + (wave1 ? 0 : kXchElems);
-    const size_t w_raw = (size_t)blockIdx.x * RW + rot;
-    const bool live = w_raw < (size_t)P.R;                                        // a padding rotation repeats the last one, stores nothing
-    const size_t w = live ? w_raw : (size_t)P.R - 1;
-    const int32_t *bara = P.bara + w * (P.n + 1);
-    const int beta = P.g.log2_base;
-    const int32_t xormask = gadget_xor_mask(L, beta);
-    const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
-
-    cplx tw1f[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1 ? 512 : 0) + q * 64 + lane];
-    if (tid < 64) tw2_lds[tid] = P.tw2[tid];
-    {   // wave 0 writes the (zero) mask polynomial, wave 1 the body X^{-barb} (mu, ..., mu), mirrors included
-        const int barb = bara[P.n] & (2 * kN2 - 1);
-        int32_t v[32];
-#pragma unroll
-        for (int m = 0; m < 32; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN2 - 1);
-            v[m] = !wave1 ? 0 : (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+    static_for<0, 8>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const cplx al = alpha[R], be = beta[R];
+        const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
+        // conj(beta) e_r   (r = 0 and r = 4 written out: without fast-math the products by 0 and 1 are not folded)
+        const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
+        const double bi = R == 0 ? -be.y : R == 4 ? -be.x : be.x * ei - be.y * er;
+        // (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024        conj(alpha) = (al.x, -al.y)
+        // (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
+        const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
+        const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
+        const double re0 = R == 0 ? pr : pr * c0r - pi * c0i, im0 = R == 0 ? pi : pr * c0i + pi * c0r;
+        const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
+        if (MARGIN) {
+            const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
+            worst = f0 > worst ? f0 : worst;
+            worst = f1 > worst ? f1 : worst;
+            worst = f2 > worst ? f2 : worst;
+            worst = f3 > worst ? f3 : worst;
         }
-        store_cur<32>(lane, v, acc_lds + (wave1 ? kImg2 : 0));
-    }
-    __syncthreads();
-    STAMP_DECL;
-
-    int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
-    wave_priority_begin(P.prio_steps);
-#pragma unroll 1
-    for (int i = 0; i < P.n; i++) {
-        wave_priority_step(i, P.prio_steps);
-        const int a = a_next;
-        a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);   // bara[n] (= barb) exists: harmless read on the last step
-        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + (wave1 ? kM : 0) + lane;
-        cplx out[K1][8];
-#pragma unroll
-        for (int d = 0; d < K1; d++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
-#pragma unroll 1
-        for (int c = 0; c < K1; c++) {
-            int32_t temp[32];
-            rotate_poly<32>(lane, a, acc_lds + c * kImg2, P.g.offset, xormask, temp);
-            STAMP(0);
-#pragma unroll 1
-            for (int p = 0; p < L; p++) {
-                cplx x[8];
-                static_for<0, 8>([&](auto rc) {
-                    constexpr int R = decltype(rc)::value;
-                    const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);
-                    const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
-                    x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
-                });
-                STAMP(1);
-                // the first KPN values of the co = 0 key chunk are requested inside the transform, between the store and the load
-                // of its second transposition (x[] is dead there; a chunk requested before the transform spills into the
-                // loop: 71.7 ms), the rest after the transform: the L2 round trip then overlaps the last radix-8 pass
-                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
-                cplx kv0[8];
-                if (KPRE) {
-                    fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch, [&]() {
-#pragma unroll
-                        for (int k2 = 0; k2 < KPN; k2++) kv0[k2] = kp[k2 * 64];
-                    });
-#pragma unroll
-                    for (int k2 = KPN; k2 < 8; k2++) kv0[k2] = kp[k2 * 64];
-                } else {
-                    fft_fwd_half(lane, x, tw1f, tw2_lds, xch);
-                }
-                STAMP(2);
-                {
-                    cplx kv1[8];
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv1[k2] = kp[(size_t)2 * kM + k2 * 64];
-                    if (!KPRE) {
-#pragma unroll
-                        for (int k2 = 0; k2 < 8; k2++) kv0[k2] = kp[k2 * 64];
-                    }
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cfma(x[k2], kv0[k2], out[0][k2]);
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[1][k2] = cfma(x[k2], kv1[k2], out[1][k2]);
-                }
-                STAMP(3);
-            }
-        }
-        STAMP(4);
-        // Both inverse half-transforms first (wave 0 then holds alpha_0, alpha_1, wave 1 beta_0, beta_1); wave 0 finishes
-        // output polynomial 0 and wave 1 polynomial 1, all four coefficient classes of it, so each wave hands over ONE
-        // block (wave 0: alpha_1, wave 1: beta_0) and a step has two barriers: the one before the hand-off is read (every
-        // rotated read of this step precedes it in every wave, so it also covers the accumulator update) and the one
-        // that ends the step.
-        fft_inv_wave(lane, out[0], tw1f, tw2_lds, xch);
-        fft_inv_wave(lane, out[1], tw1f, tw2_lds, xch);
-        STAMP(5);
-        WAVE_LDS_FENCE();
-        if (wave1) {           // (wave-uniform branches, not selects: a select would copy the block into new registers)
-#pragma unroll
-            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[0][r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[1][r];
-        }
-        __syncthreads();
-        STAMP(6);
-        cplx oth[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
-        STAMP(7);
-        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) {
-            static_for<0, 8>([&](auto rc) {
-                constexpr int R = decltype(rc)::value;
-                const cplx al = alpha[R], be = beta[R];
-                const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
-                // conj(beta) e_r   (r = 0 and r = 4 written out: without fast-math the products by 0 and 1 are not folded)
-                const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
-                const double bi = R == 0 ? -be.y : R == 4 ? -be.x : be.x * ei - be.y * er;
-                // (conj(alpha) + conj(beta) e_r) c_r      -> coefficients jj, jj+1024        conj(alpha) = (al.x, -al.y)
-                // (conj(alpha) - conj(beta) e_r) c_{r+8}  -> coefficients jj+512, jj+1536
-                const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
-                const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
-                const double re0 = R == 0 ? pr : pr * c0r - pi * c0i, im0 = R == 0 ? pi : pr * c0i + pi * c0r;
-                const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
-                if (MARGIN) {
-                    const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
-                    worst = f0 > worst ? f0 : worst;
-                    worst = f1 > worst ? f1 : worst;
-                    worst = f2 > worst ? f2 : worst;
-                    worst = f3 > worst ? f3 : worst;
-                }
-                const int jlo = kMir + lane + 64 * R;
-                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
-                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
-                ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
-                const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
-                ap[jlo + 1536] = last;
-                if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
-            });
-        };
-        if (wave1) finish(oth, out[1], acc_lds + kImg2);
-        else finish(out[0], oth, acc_lds);
-        STAMP(8);
-        __syncthreads();
-        STAMP(9);
-    }
-    STAMP_FLUSH(P.diag, wib);
-
-    if (!live) return;
-    const int tid_e = ((wib & 1) << 6) + lane_id_fresh();      // thread within its rotation, rebuilt: threadIdx.x need not survive the loop
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, tid_e == 0);
-    int32_t *ext = P.ext + w * (kN2 + 1);
-    for (int j = tid_e; j < kN2; j += 128) {
-        const int32_t v = acc_lds[kMir + j];
-        if (j == 0) ext[0] = v;
-        else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
-    }
-    if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
+        const int jlo = kMir + lane + 64 * R;
+        ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
+        ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
+        ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
+        const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
+        ap[jlo + 1536] = last;
+        if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
+    });
 }
 
-// ---- N = 2048, rotated words exchanged instead of computed twice (round 4) -------------------------------------------
-// blind_rotate_kernel_n2048 has BOTH waves of a rotation rotate and offset all 32 coefficient classes of both accumulator
-// polynomials (each needs every coefficient for its half of the frequencies): 2 x 406 of a wave's ~4950 instructions per
-// step, half of them scalar address arithmetic.  Here wave c rotates only polynomial c — the one it also updates, so an
-// accumulator polynomial is private to its wave and its update needs no barrier —, runs the L transforms of that
-// polynomial's digits, then parks the 32 rotated words (8 KB) in its transposition buffer, which is idle at that point;
-// after the barrier it takes the other wave's words from the other buffer and KEEPS that buffer for the remaining
-// transforms (the other wave does the same with this one's).  The hand-off of the inverse half-transforms swaps the
-// buffers back.  A wave's LDS operations execute in order, so a buffer a wave has just read is free for it to write;
-// the buffer it gave away it does not touch until the next exchange.  Still two barriers per step, one rotation per
-// wave instead of two, 16 more 16-byte LDS operations.  Same words as blind_rotate_kernel_n2048.
+// ---- N = 2048: the blind-rotation kernel (round 4; round 3's blind_rotate_kernel_n2048 is in the history) ------------------
+// Two waves per rotation, each computing one half of the frequencies of every transform (above).  Each half needs every
+// coefficient of a rotated polynomial, and until round 3 BOTH waves rotated and offset all 32 coefficient classes of both
+// accumulator polynomials: 2 x 406 of a wave's ~4950 instructions per step, half of them scalar address arithmetic.
+// Here wave c rotates only polynomial c — the one it also updates, so an accumulator polynomial is private to its wave
+// and its update needs no barrier —, runs the L transforms of that polynomial's digits, then parks the 32 rotated words
+// (8 KB) in its transposition buffer, which is idle at that point; after the barrier it takes the other wave's words from
+// the other buffer and KEEPS that buffer for the remaining transforms (the other wave does the same with this one's).
+// Then both inverse half-transforms; wave 0 recombines output polynomial 0 and wave 1 polynomial 1 (finish_2048), so each
+// hands ONE 8 KB block over, and that hand-off swaps the buffers back.  A wave's LDS operations execute in order, so a
+// buffer a wave has just read is free for it to write; the buffer it gave away it does not touch until the next exchange.
+// Two barriers per step, one rotation per wave, 16 16-byte LDS operations for the exchange.
+// RW rotations per workgroup advance in lockstep (the barriers are workgroup-wide): the transformed key of N = 2048 sets
+// (124 MB at n = 630, l = 3) does not stay in the 4 MB L2 of an XCD once workgroups drift apart, and rotations that read the
+// same key values at the same time share one trip to the Infinity Cache (one / two / four per workgroup: 53.4 / 44.5 / 47.4 ms).
+// Measured against the round-3 kernel on one device, config 4b (profiles/r04/r04a_4b.jsonl, r04a_phase.txt): 44.5 vs 44.9 ms;
+// in the stamped builds the rotate phase shrinks from 8.9 k to 3.9 k cycles of a 48 k-cycle step and the other phases take
+// up most of what it frees — a wave's issue slots were being used by its partner, not idle.
 template <int L, bool MARGIN = false, int RW = 2>
 __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048Args P)
 {
@@ -1957,7 +1705,11 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #ifndef TFHE_N2048X_KPN
 #define TFHE_N2048X_KPN 2
 #endif
-    constexpr int KPN = TFHE_N2048X_KPN;      // co = 0 key values requested inside the transform
+    // The first KPN values of the co = 0 key chunk are requested inside the transform, between the store and the load of its
+    // second transposition (x[] is dead there; a chunk requested before the transform spills into the loop: 71.7 ms), the
+    // rest after the transform: the L2 round trip then overlaps the last radix-8 pass.  Round 3, one device, 4096 rotations of
+    // config 4b: 0: 54.2 ms, 1: 49.8, 2: 48.0, 3: 49.9, 4: 49.3-50.1, 6: 48.6-49.2, 8: 49.4-50.4
+    constexpr int KPN = TFHE_N2048X_KPN;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
@@ -2003,8 +1755,9 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
         wave_priority_step(i, P.prio_steps);
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);
-        // (lane and wave half rebuilt per step, the half as a per-lane value on purpose — see blind_rotate_kernel_n2048: what is
-        //  derived from them is then recomputed here instead of living, and being spilled, across the whole loop)
+        // (lane and wave half rebuilt per step: what is derived from them is recomputed here instead of living, and being spilled,
+        //  across the whole loop.  The half as a PER-LANE value on purpose: the per-wave constants of the radix-2 split are then
+        //  selected per lane instead of by scalar branches — round 3, one device, config 4b: 44.6 ms against 46.5 ms)
         const int lane = lane_id_fresh();
         int wvv;
         asm volatile("v_mov_b32 %0, %1" : "=v"(wvv) : "s"(wv));
@@ -2090,33 +1843,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #pragma unroll
         for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
         STAMP(7);
-        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) {
-            static_for<0, 8>([&](auto rc) {
-                constexpr int R = decltype(rc)::value;
-                const cplx al = alpha[R], be = beta[R];
-                const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);
-                const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
-                const double bi = R == 0 ? -be.y : R == 4 ? -be.x : be.x * ei - be.y * er;
-                const double pr = al.x + br, pi = -al.y + bi, mr = al.x - br, mi = -al.y - bi;
-                const double c0r = cos_pi32(R), c0i = -sin_pi32(R), c1r = cos_pi32(R + 8), c1i = -sin_pi32(R + 8);
-                const double re0 = R == 0 ? pr : pr * c0r - pi * c0i, im0 = R == 0 ? pi : pr * c0i + pi * c0r;
-                const double re1 = mr * c1r - mi * c1i, im1 = mr * c1i + mi * c1r;
-                if (MARGIN) {
-                    const double f0 = frac_dist(re0), f1 = frac_dist(im0), f2 = frac_dist(re1), f3 = frac_dist(im1);
-                    worst = f0 > worst ? f0 : worst;
-                    worst = f1 > worst ? f1 : worst;
-                    worst = f2 > worst ? f2 : worst;
-                    worst = f3 > worst ? f3 : worst;
-                }
-                const int jlo = kMir + lane + 64 * R;
-                ap[jlo] = (int32_t)((uint32_t)ap[jlo] + (uint32_t)round_to_torus32(re0));
-                ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + (uint32_t)round_to_torus32(im0));
-                ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + (uint32_t)round_to_torus32(re1));
-                const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + (uint32_t)round_to_torus32(im1));
-                ap[jlo + 1536] = last;
-                if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);
-            });
-        };
+        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) { finish_2048<MARGIN>(lane, alpha, beta, ap, worst); };
         if (wave1) finish(oth, out[1], acc_own);
         else finish(out[0], oth, acc_own);
         WAVE_LDS_FENCE();       // (no barrier: only this wave reads or writes acc_own, and the buffer just read is this wave's again)
@@ -2135,6 +1862,150 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
         else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
     }
     if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
+}
+
+// ---- any single-key parameter set (round 4): run-time mask size k <= 4 and decomposition length l, N = 1024 or 2048 ----
+// SchemeParameters is an unvalidated struct and tlwe_mask_size a free keyword in the reference (api.jl:4-21,30,55): a
+// parameter set it accepts must not be refused here because no specialised kernel was instantiated for it.  This kernel
+// takes what the others leave (k >= 3, l >= 5, N = 2048 with k >= 2): one wave per rotation, one wave per SIMD, nothing
+// tuned.  The accumulator images (k + 1 polynomials) live in global memory (L2-resident; a wave reads back only what it
+// wrote itself, ordered by a workgroup-scope fence per step, as in mk_blind_rotate_kernel_general's ACCG variant), the
+// k + 1 spectrum accumulators of a step in LDS ((k + 1) x N/1024 x 8 KB), so no register array depends on k or l.
+// N = 2048: the radix-2 split of blind_rotate_kernel_n2048x with both halves computed by the one wave, one after the other.
+struct BrGenArgs {
+    DiagArgs diag;
+    const int32_t *bara;  // [R][n+1]
+    const cplx *bk;       // [n][L][K1][K1][H][8][64], H = N / 1024 halves
+    int32_t *ext;         // [R][(K1-1)*N + 1]
+    int32_t *acc;         // [R][K1][kMir + N] accumulator images
+    const cplx *tw1f;     // [H][8][64]: Tables::tw1f (N = 1024) or the two tables of Br2048Args::tw1f2
+    const cplx *tw2;      // [8][8]
+    Gadget g;
+    int32_t n, mu, K1, L, R;
+};
+
+template <int NBLK /* N / 64: 16 or 32 */, bool MARGIN = false>
+__global__ __launch_bounds__(64, 1) void blind_rotate_kernel_general(BrGenArgs P)
+{
+    constexpr int N = 64 * NBLK, H = NBLK / 16, kImgN = kMir + N;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx *xch = reinterpret_cast<cplx *>(smem);                 // [kXchElems]
+    cplx *tw2_lds = xch + kXchElems;                            // [8][8]
+    cplx *spec = tw2_lds + 64;                                  // [K1][H][8][64] spectrum accumulators of the step
+    const int lane = threadIdx.x;
+    const size_t w = blockIdx.x;
+    const int K1 = P.K1, L = P.L;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    int32_t *acc = P.acc + w * (size_t)K1 * kImgN;
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[H][8];
+#pragma unroll
+    for (int h = 0; h < H; h++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) tw1f[h][q] = P.tw1f[h * 512 + q * 64 + lane];
+    tw2_lds[lane] = P.tw2[lane];
+    {   // accum = (0, ..., 0, X^{-barb} (mu, ..., mu))     bootstrap.jl:54-56,78
+        const int barb = bara[P.n] & (2 * N - 1);
+        int32_t v[NBLK];
+        for (int c = 0; c < K1; c++) {
+#pragma unroll
+            for (int m = 0; m < NBLK; m++) {
+                const int idx = (lane + 64 * m + barb) & (2 * N - 1);
+                v[m] = c + 1 < K1 ? 0 : (idx & N) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+            }
+            store_cur<NBLK>(lane, v, acc + c * kImgN);
+        }
+    }
+    auto acc_fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    acc_fence();
+
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = bara[i] & (2 * N - 1);
+        const cplx *key = P.bk + (size_t)i * ((size_t)L * K1 * K1 * H * kM) + lane;
+        for (int j = 0; j < K1 * H * 8; j++) spec[j * 64 + lane] = mk(0.0, 0.0);
+        WAVE_LDS_FENCE();
+#pragma unroll 1
+        for (int c = 0; c < K1; c++) {
+            int32_t temp[NBLK];
+            rotate_poly<NBLK>(lane, a, acc + c * kImgN, P.g.offset, xormask, temp);
+#pragma unroll 1
+            for (int p = 0; p < L; p++) {
+#pragma unroll
+                for (int h = 0; h < H; h++) {
+                    cplx x[8];
+                    if constexpr (H == 1) {
+                        int32_t t16[16];
+#pragma unroll
+                        for (int m = 0; m < 16; m++) t16[m] = temp[m];
+                        load_digits2(t16, p + 1, beta, x);
+                    } else {
+                        const double sg = h ? -0.70710678118654752440 : 0.70710678118654752440;
+                        static_for<0, 8>([&](auto rc) {
+                            constexpr int R = decltype(rc)::value;
+                            const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);
+                            const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
+                            x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, h != 0);
+                        });
+                    }
+                    fft_fwd_wave(lane, x, tw1f[h], tw2_lds, xch);
+                    WAVE_LDS_FENCE();
+                    // out[co] += D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128)
+#pragma unroll 1
+                    for (int co = 0; co < K1; co++) {
+                        const cplx *kp = key + ((size_t)((p * K1 + c) * K1 + co) * H + h) * kM;
+                        cplx *sp = spec + (size_t)(co * H + h) * kM + lane;
+#pragma unroll
+                        for (int k2 = 0; k2 < 8; k2++) sp[k2 * 64] = cfma(x[k2], kp[k2 * 64], sp[k2 * 64]);
+                    }
+                    WAVE_LDS_FENCE();
+                }
+            }
+        }
+        // every rotated read of this step is done: inverse transforms, rounding, accumulator update (bootstrap.jl:22)
+#pragma unroll 1
+        for (int co = 0; co < K1; co++) {
+            cplx y[H][8];
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) y[h][k2] = spec[(size_t)(co * H + h) * kM + k2 * 64 + lane];
+                WAVE_LDS_FENCE();
+                fft_inv_wave(lane, y[h], tw1f[h], tw2_lds, xch);
+                WAVE_LDS_FENCE();
+            }
+            if constexpr (H == 1) {
+                int32_t accr[16];
+                load_cur<16>(lane, acc + co * kImgN, accr);
+                untwist_add2<MARGIN>(y[0], accr, &worst);
+                store_cur<16>(lane, accr, acc + co * kImgN);
+            } else {
+                finish_2048<MARGIN>(lane, y[0], y[H - 1], acc + co * kImgN, worst);
+            }
+        }
+        acc_fence();
+    }
+
+    // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
+    int32_t *ext = P.ext + w * ((size_t)(K1 - 1) * N + 1);
+    for (int c = 0; c + 1 < K1; c++)
+#pragma unroll
+        for (int m = 0; m < NBLK; m++) {
+            const int j = lane + 64 * m;
+            const int32_t v = acc[c * kImgN + kMir + j];
+            if (j == 0) ext[(size_t)c * N] = v;
+            else ext[(size_t)c * N + N - j] = (int32_t)(0u - (uint32_t)v);
+        }
+    if (lane == 0) ext[(size_t)(K1 - 1) * N] = acc[(K1 - 1) * kImgN + kMir];
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
 #ifndef TFHE_KERNEL_TEMPLATES_ONLY     // (the translation units that only instantiate kernel templates — mk_g2_*.hip — leave these out)

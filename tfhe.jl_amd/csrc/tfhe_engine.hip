@@ -85,14 +85,12 @@ struct tfhe_ctx {
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
     int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
+    int br_general = 0;          // tfhe_set_option("br_general", 1): every single-key blind rotation on blind_rotate_kernel_general (cross-check of the specialised kernels)
     int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels in a second launch (launch_blind_rotate)
     int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
                                  //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
                                  //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
                                  // measured (interleaved A/B): 1 gate 1.83 vs 1.91 ms (l = 2), 2.76 vs 3.07 ms (l = 3); 32 gates: 2 % slower
-    int br_variant = 0;          // 0 = default (4), 1 = round-1 baseline kernel (-DTFHE_BUILD_BASELINE builds only), 2 = v3 with the whole key chunk
-                                 // requested a transform ahead, 3 = v3 with half of it ahead and the rest inside / after the transform,
-                                 // 4 = 3 with the pass-B twiddles in registers instead of a wave-private LDS table
 
     // tables
     cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
@@ -120,7 +118,7 @@ struct tfhe_ctx {
     DevBuf bara, ext, map, io[4], diag, abar, mk_acc;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
-    int n2048_rw = 0;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 0|1|2|4); 0 = one up to
+    int n2048_rw = 0;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 0|1|2); 0 = one up to
                                    //  one rotation per CU — the pair would leave half the CUs idle: 7.9 vs 9.0 ms at 64 rotations — two beyond)
     int mkg_rw = 0;                // any-party kernel: rotations per workgroup, in lockstep (0: two; otherwise a cap, at most 4 and what fits in LDS)
     int mkg_variant = 0;           // 4- / 8-party shipped sets: 0 = two-wave kernel with compile-time (parties, l), 1 = the any-party kernel
@@ -138,7 +136,6 @@ struct tfhe_ctx {
     uint32_t submits = 0;
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
-    int n2048_variant = 0;       // tfhe_set_option("n2048_variant", 0 | 1 | 2): 1 = blind_rotate_kernel_n2048 (both waves rotate both polynomials), 2 = blind_rotate_kernel_n2048x (rotated words exchanged); 0 = default (2)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
@@ -254,12 +251,15 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d or %d (got %d)", kN, kN2, p.N);
         return fail(TFHE_ERR_UNSUPPORTED, buf);
     }
-    if (p.N == kN2 && (p.k != 1 || p.parties != 1))
-        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: N = 2048 is supported with tlwe_mask_size 1, single key");
-    if (p.k != 1 && p.k != 2) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: this build supports tlwe_mask_size k = 1 or 2");
+    // Single key: every (k <= 4, l with l * beta <= 32, N in {1024, 2048}) runs — on a specialised kernel where one was
+    // instantiated (k <= 2 and l <= 4 at N = 1024, k = 1 and l <= 4 at N = 2048), on blind_rotate_kernel_general otherwise:
+    // SchemeParameters is unvalidated and tlwe_mask_size a free keyword in the reference (api.jl:4-21,30,55).
+    if (p.N == kN2 && p.parties != 1)
+        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key is supported with N = 1024 only (the reference ships no other multi-key set, mk_api.jl:4-34)");
+    if (p.k > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: tlwe_mask_size k > 4 unsupported");
     if (p.k != 1 && p.parties != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key needs tlwe_mask_size 1 (as the reference, mk_internals.jl:89-91)");
-    if (p.bs_l > (p.parties > 1 ? 8 : 4))
-        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 4 (single key) / > 8 (multi-key) unsupported");
+    if (p.parties > 1 && p.bs_l > 8)
+        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 8 (multi-key) unsupported");
     if (p.parties > 8) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: more than 8 parties unsupported");
     if (p.n + 1 > 1024) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: lwe_size + 1 > 1024 unsupported");
 
@@ -651,13 +651,14 @@ static int32_t prepare_diag(tfhe_ctx *c, size_t R, hipStream_t s, DiagArgs &d)
     return TFHE_OK;
 }
 
+// Tuned kernels are instantiated for the decomposition lengths the shipped parameter sets use: l = 2 (tfhe_parameters_80,
+// api.jl:30-52) and l = 3 (tfhe_parameters_128, api.jl:55-69; BASELINE config 4b), with either mask size at N = 1024.
+// Every other set the reference would accept runs on blind_rotate_kernel_general.
 #define BR_CASES(LAUNCH)                                                                                           \
     switch (c->P.bs_l) {                                                                                           \
-    case 1: LAUNCH(1); break;                                                                                      \
     case 2: LAUNCH(2); break;                                                                                      \
     case 3: LAUNCH(3); break;                                                                                      \
-    case 4: LAUNCH(4); break;                                                                                      \
-    default: return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: bs_l = %d unsupported", c->P.bs_l);            \
+    default: return c->set_err(TFHE_ERR_STATE, "blind rotate: no tuned kernel for bs_l = %d", c->P.bs_l);          \
     }
 
 static void name_kernel(tfhe_ctx *c, const char *fmt, ...)
@@ -688,42 +689,54 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
     a.prio_steps = (int32_t)((int64_t)c->P.n * c->br_prio_pct / 100);
     a.R = (int32_t)R;
     const int L = c->P.bs_l;
+    const bool tuned = c->P.N == kN2 ? (c->P.k == 1 && L == 3) : (c->P.k <= 2 && (L == 2 || L == 3));
+    if (!tuned || c->br_general) {
+        // any (k <= 4, l, N): one wave per rotation, accumulator images in global memory, spectrum accumulators in LDS
+        const int K1 = c->P.k + 1, H = c->P.N / kN;
+        const size_t img = (size_t)kMir + c->P.N;
+        BrGenArgs g;
+        g.diag = a.diag; g.bara = a.bara; g.bk = a.bk; g.ext = a.ext; g.g = c->g; g.n = a.n; g.mu = mu; g.K1 = K1; g.L = L; g.R = (int32_t)R;
+        HIP_TRY(c, c->mk_acc.reserve((first + R) * K1 * img * sizeof(int32_t)));
+        g.acc = (int32_t *)c->mk_acc.p + first * K1 * img;
+        g.tw1f = c->P.N == kN2 ? (const cplx *)(c->d_tables + kTableElems) : c->T.tw1f;
+        g.tw2 = c->T.tw2;
+        const size_t ldsg = (kXchElems + 64 + (size_t)K1 * H * kM) * sizeof(cplx);
+#define LAUNCH_GEN(NB, DG)                                                                                         \
+        do {                                                                                                       \
+            if (ldsg > 64 * 1024)                                                                                  \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_general<NB, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
+            hipLaunchKernelGGL((blind_rotate_kernel_general<NB, DG>), dim3((unsigned)R), dim3(64), ldsg, s, g);     \
+        } while (0)
+        if (c->P.N == kN2) { if (dg) LAUNCH_GEN(32, true); else LAUNCH_GEN(32, false); }
+        else { if (dg) LAUNCH_GEN(16, true); else LAUNCH_GEN(16, false); }
+#undef LAUNCH_GEN
+        HIP_TRY(c, hipGetLastError());
+        name_kernel(c, "blind_rotate_kernel_general(N=%d,k=%d,l=%d)", c->P.N, c->P.k, L);
+        return TFHE_OK;
+    }
     if (c->P.N == kN2) {
+        // BASELINE config 4b's shape (k = 1, l = 3).  n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation
+        // per workgroup, up to one rotation per CU: the pair would leave half the CUs idle).  Four per workgroup — the whole CU
+        // in phase — were measured slower: 47.4 vs 44.5 ms per 4096 rotations (profiles/r04/r04a_4b.jsonl).
         Br2048Args b;
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
-        // n2048_rw rotations per workgroup in lockstep (2: default; 1: one rotation per workgroup)
         const int rw = c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);
         const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
-        const bool xv = c->n2048_variant != 1;
-#define LAUNCH_2048_K(KERNEL, LL, DG, RWV)                                                                         \
+#define LAUNCH_2048(DG, RWV)                                                                                       \
         do {                                                                                                       \
             if (ldsb > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)KERNEL<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
-            hipLaunchKernelGGL((KERNEL<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b);                    \
+                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_n2048x<3, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+            hipLaunchKernelGGL((blind_rotate_kernel_n2048x<3, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b); \
         } while (0)
-#define LAUNCH_2048_RW(LL, DG, RWV)                                                                               \
-        do {                                                                                                       \
-            if (xv) LAUNCH_2048_K(blind_rotate_kernel_n2048x, LL, DG, RWV);                                        \
-            else LAUNCH_2048_K(blind_rotate_kernel_n2048, LL, DG, RWV);                                            \
-        } while (0)
-#define LAUNCH_2048(LL)                                                                                            \
-        do {                                                                                                       \
-            if (rw == 4 && dg) LAUNCH_2048_RW(LL, true, 4);                                                        \
-            else if (rw == 4) LAUNCH_2048_RW(LL, false, 4);                                                        \
-            else if (rw == 2 && dg) LAUNCH_2048_RW(LL, true, 2);                                                   \
-            else if (rw == 2) LAUNCH_2048_RW(LL, false, 2);                                                        \
-            else if (dg) LAUNCH_2048_RW(LL, true, 1);                                                              \
-            else LAUNCH_2048_RW(LL, false, 1);                                                                     \
-        } while (0)
-        BR_CASES(LAUNCH_2048)
-#undef LAUNCH_2048_RW
-#undef LAUNCH_2048_K
+        if (rw == 2 && dg) LAUNCH_2048(true, 2);
+        else if (rw == 2) LAUNCH_2048(false, 2);
+        else if (dg) LAUNCH_2048(true, 1);
+        else LAUNCH_2048(false, 1);
 #undef LAUNCH_2048
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, xv ? "blind_rotate_kernel_n2048x<%d,rw%d>" : "blind_rotate_kernel_n2048<%d,rw%d>", L, rw);
-        (void)nblk;
+        name_kernel(c, "blind_rotate_kernel_n2048x<%d,rw%d>", L, rw);
         return TFHE_OK;
     }
     if (c->P.k == 2) {
@@ -735,10 +748,10 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         // almost as long as a full one, so the batch is dealt out in ceil(R / 1792) EQUALLY full rounds: every workgroup
         // gets floor or ceil of R / (rounds x CUs) rotations, its other waves idle at the barriers (4096 rotations: rounds
         // of 6, 5 and 5 per CU).  Option k2_rw: 0 / 7 = this rule, 1 = single-rotation workgroups.
-        const size_t cus = (size_t)c->cu_count;
         // (Round 4, measured dead end: groups of THREE in lockstep, two such workgroups per CU, handed out by the dispatcher as
         //  slots free up — no rounds, six rotations per CU: 1792 rotations 15.8 vs 11.4 ms, 4096: 30.8 vs 29.9, 7168: 49.9 vs 43.5,
-        //  16384: 105.5 vs 100.1; gpurun_out/r04b_k2.jsonl -> profiles/r04/)
+        //  16384: 105.5 vs 100.1; profiles/r04/r04b_k2.jsonl)
+        const size_t cus = (size_t)c->cu_count;
         const bool grouped = !dg && (c->k2_rw == 7 || c->k2_rw == 0);     // (never slower than single-rotation workgroups: 6.7 vs 6.9 ms at 64 rotations, 6.8 vs 7.6 at 512)
         if (grouped) {
             const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
@@ -765,9 +778,8 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         name_kernel(c, "blind_rotate_kernel_k2<%d>", L);
         return TFHE_OK;
     }
-    const int brv = c->br_variant ? c->br_variant : 4;                     // 0 = default: half key chunk ahead + pass-B twiddles in registers
     const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
-    if ((tiny >= 0 && (int64_t)R <= tiny) && brv >= 2 && L <= 3) {     // (l = 4 would be 16 waves of 128 registers: spills)
+    if (tiny >= 0 && (int64_t)R <= tiny) {
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
@@ -778,18 +790,14 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
             hipLaunchKernelGGL((blind_rotate_kernel_h2<LL, DG>), dim3((unsigned)R), dim3(256 * LL), ldsh, s, a, ht); \
         } while (0)
 #define LAUNCH_H2(LL) do { if (dg) LAUNCH_H2_(LL, true); else LAUNCH_H2_(LL, false); } while (0)
-        switch (L) {                       // l = 4 (16 waves of 128 registers: spills) is never selected and not instantiated
-        case 1: LAUNCH_H2(1); break;
-        case 2: LAUNCH_H2(2); break;
-        default: LAUNCH_H2(3); break;
-        }
+        BR_CASES(LAUNCH_H2)
 #undef LAUNCH_H2
 #undef LAUNCH_H2_
         HIP_TRY(c, hipGetLastError());
         name_kernel(c, "blind_rotate_kernel_h2<%d>", L);
         return TFHE_OK;
     }
-    if ((c->br_small >= 0 && (int64_t)R <= c->br_small) && brv >= 2) {
+    if (c->br_small >= 0 && (int64_t)R <= c->br_small) {
         // 27.4 KB of LDS and < 256 registers per wave: four workgroups per CU, 1024 rotations resident at two waves per SIMD
         const size_t ldsw = kW2LdsBytes;
         // two rotations per workgroup (lockstep through the step barrier, key reads shared in L1) when that fills the CUs evenly: from
@@ -807,12 +815,12 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         name_kernel(c, pairs ? "blind_rotate_kernel_w2<%d,rw2>" : "blind_rotate_kernel_w2<%d>", L);
         return TFHE_OK;
     }
-    if (brv >= 2) {
+    {
+        // one wave per rotation: half of a transform's key chunk requested a transform ahead, pass-B twiddles in registers
+        // (round 3's <l, 16> / <l, 8, tw2 in LDS> variants were A/B scaffolding and are gone); four rotations per workgroup in
+        // lockstep once the batch puts two waves on most SIMDs (option v3_rw: 0 = by batch size, 1, 4)
         const size_t lds3 = kV3LdsBytes;
-        const bool half = (brv >= 3), t2r = (brv == 4);
-        // default variant: four rotations per workgroup in lockstep once the batch puts two waves
-        // on most SIMDs (option v3_rw: 0 = by batch size, 1, 4)
-        const bool group = t2r && (c->v3_rw == 4 || (c->v3_rw == 0 && R >= 1536));      // (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
+        const bool group = c->v3_rw == 4 || (c->v3_rw == 0 && R >= 1536);      // (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
 #define LAUNCH_V3_GROUP(LL, DG)                                                                                    \
         do {                                                                                                       \
             HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_v3<LL, 8, true, DG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds3))); \
@@ -821,31 +829,15 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 #define LAUNCH_V3(LL)                                                                                              \
         if (group && dg) LAUNCH_V3_GROUP(LL, true);                                                                \
         else if (group) LAUNCH_V3_GROUP(LL, false);                                                                \
-        else if (t2r && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);     \
-        else if (t2r) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, false>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
-        else if (half && dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);   \
-        else if (half) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a);        \
-        else if (dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, true>), dim3((unsigned)R), dim3(64), lds3, s, a);          \
-        else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 16, false, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
+        else if (dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);     \
+        else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
         BR_CASES(LAUNCH_V3)
 #undef LAUNCH_V3
 #undef LAUNCH_V3_GROUP
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, group ? "blind_rotate_kernel_v3<%d,%d,tw2reg,rw4>" : t2r ? "blind_rotate_kernel_v3<%d,%d,tw2reg>" : "blind_rotate_kernel_v3<%d,%d>", L, half ? 8 : 16);
+        name_kernel(c, group ? "blind_rotate_kernel_v3<%d,8,tw2reg,rw4>" : "blind_rotate_kernel_v3<%d,8,tw2reg>", L);
         return TFHE_OK;
     }
-#ifdef TFHE_BUILD_BASELINE
-    const size_t lds = 2 * kN * 4 + kXchElems * sizeof(cplx);
-#define LAUNCH_V1(LL) hipLaunchKernelGGL((blind_rotate_kernel<LL, 2>), dim3((unsigned)R), dim3(64), lds, s, a)
-    BR_CASES(LAUNCH_V1)
-#undef LAUNCH_V1
-    HIP_TRY(c, hipGetLastError());
-    name_kernel(c, "blind_rotate_kernel<%d,2>", L);
-    c->diag_rows = 0;      // the baseline kernel has no DIAG instantiation
-    return TFHE_OK;
-#else
-    return c->set_err(TFHE_ERR_UNSUPPORTED, "blind rotate: br_variant 1 (round-1 baseline kernel) is compiled only with -DTFHE_BUILD_BASELINE");
-#endif
 }
 
 // A batch whose size is not a multiple of what the chip holds pays for its last, partly filled round as for a full one
@@ -867,12 +859,12 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     int32_t rc = prepare_diag(c, R, s, diag);
     if (rc) return rc;
     const size_t resident = 8 * (size_t)c->cu_count;          // rotations of blind_rotate_kernel_v3 on the chip
-    const bool family = c->P.N == kN && c->P.k == 1 && (c->br_variant == 0 || c->br_variant == 4) && c->br_split && c->br_small > 0;
+    const bool family = c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general && c->br_split && c->br_small > 0;
     const size_t small = family ? (size_t)c->br_small : 0;
     const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
     size_t head = 0;                                          // rotations of the first launch; 0: one launch
     if (family && R > resident && R % resident > 0 && R % resident <= small) head = R - R % resident;
-    else if (family && R > small && small <= resident / 2 && tiny > 0 && R - small <= (size_t)tiny && c->P.bs_l <= 3) head = small;
+    else if (family && R > small && small <= resident / 2 && tiny > 0 && R - small <= (size_t)tiny) head = small;
     if (head) {
         rc = launch_blind_rotate_part(c, 0, head, mu, s, diag);
         if (rc) return rc;
@@ -1230,7 +1222,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_split = c->br_split; t->br_variant = c->br_variant; t->n2048_rw = c->n2048_rw; t->n2048_variant = c->n2048_variant; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
+    t->br_tiny = c->br_tiny; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
     return TFHE_OK;
 }
 
@@ -1692,8 +1684,9 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     a.n = n; a.mu = (int32_t)(1u << 29); a.R = (int32_t)B;
     a.prio_steps = (int32_t)((int64_t)NP * n * c->br_prio_pct / 100);
     const size_t lds = (size_t)(NP + 1) * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
-    const bool special = (NP == 2 && c->P.bs_l >= 2 && c->P.bs_l <= 4 && !c->mk_force_general);
-    if (special && c->mk_variant == 2 && c->P.bs_l == 4) {     // (l = 2 leaves one transform per wave and source: no gain)
+    // 2 parties with l = 4 (mktfhe_parameters_2party, mk_api.jl:4-10): the tuned kernels; any other shape: the any-party kernel
+    const bool special = (NP == 2 && c->P.bs_l == 4 && !c->mk_force_general);
+    if (special && c->mk_variant == 2) {
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
         // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four)
         const int rw = c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
@@ -1713,15 +1706,8 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 #undef LAUNCH_MK2
         name_kernel(c, "mk_blind_rotate_kernel_w2<%d>", c->P.bs_l);
     } else if (special) {
-#define LAUNCH_MK(LL)                                                                                              \
-        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, true>), dim3((unsigned)B), dim3(64), lds, s, a);   \
-        else hipLaunchKernelGGL((mk_blind_rotate_kernel<LL, false>), dim3((unsigned)B), dim3(64), lds, s, a)
-        switch (c->P.bs_l) {
-        case 2: LAUNCH_MK(2); break;
-        case 3: LAUNCH_MK(3); break;
-        default: LAUNCH_MK(4); break;
-        }
-#undef LAUNCH_MK
+        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<4, true>), dim3((unsigned)B), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((mk_blind_rotate_kernel<4, false>), dim3((unsigned)B), dim3(64), lds, s, a);
         name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
 #ifndef TFHE_NO_G2      // (-DTFHE_NO_G2: quick development builds without the many-party two-wave kernel, 1 instead of 5 minutes)
     } else if (!c->mk_force_general && c->mkg_variant != 1 && ((NP == 4 && c->P.bs_l == 5) || (NP == 8 && c->P.bs_l == 8))) {
@@ -1764,9 +1750,10 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         // accumulators in global memory: LDS holds only the transposition buffer, eight waves fit a CU whatever P is
         const bool accg = c->mkg_acc < 0 ? NP > 4 : c->mkg_acc != 0;
         const size_t lds_rot = accg ? (kXchElems + 64) * sizeof(cplx) : lds;
-        int rw = (int)std::min<size_t>(4, (160 * 1024) / lds_rot);
-        rw = std::min(rw, c->mkg_rw > 0 ? c->mkg_rw : 2);      // default two: 82 vs 86 ms (four or one) at 4 parties, 476 vs 481 / 765 at 8
-        if (B < 2) rw = 1;
+        // (two rotations per workgroup: 82 vs 86 ms with four or one at 4 parties, 476 vs 481 / 765 at 8 — round 2; the three- and
+        //  four-rotation instantiations are gone)
+        int rw = (int)std::min<size_t>(2, (160 * 1024) / lds_rot);
+        if (c->mkg_rw == 1 || B < 2 || rw < 1) rw = 1;
         const size_t ldsg = (size_t)rw * lds_rot;
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         ga.acc = nullptr;
@@ -1783,12 +1770,8 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
             else hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, false>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
         } while (0)
 #define LAUNCH_MKG_RW(RWV) do { if (dg) LAUNCH_MKG(true, RWV); else LAUNCH_MKG(false, RWV); } while (0)
-        switch (rw) {
-        case 4: LAUNCH_MKG_RW(4); break;
-        case 3: LAUNCH_MKG_RW(3); break;
-        case 2: LAUNCH_MKG_RW(2); break;
-        default: LAUNCH_MKG_RW(1); break;
-        }
+        if (rw == 2) LAUNCH_MKG_RW(2);
+        else LAUNCH_MKG_RW(1);
 #undef LAUNCH_MKG_RW
 #undef LAUNCH_MKG
         name_kernel(c, accg ? "mk_blind_rotate_kernel_general(P=%d,L=%d,acc=global)" : "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
@@ -2026,14 +2009,10 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         }
         return TFHE_OK;
     }
-    if (!strcmp(name, "br_variant")) {
-        if (value < 0 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_variant must be 0 (by decomposition length), 1, 2, 3 or 4");
-        c->br_variant = (int)value;
-        return TFHE_OK;
-    }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_prio_pct")) {
         if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
         c->br_prio_pct = (int)value;
@@ -2062,13 +2041,8 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
-    if (!strcmp(name, "n2048_variant")) {
-        if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_variant must be 0 (default), 1 (both waves rotate) or 2 (rotated words exchanged)");
-        c->n2048_variant = (int)value;
-        return TFHE_OK;
-    }
     if (!strcmp(name, "n2048_rw")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 0 (by batch size), 1, 2 or 4");
+        if (value != 0 && value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 0 (by batch size), 1 or 2");
         c->n2048_rw = (int)value;
         return TFHE_OK;
     }
@@ -2083,7 +2057,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "mkg_rw")) {
-        if (value < 0 || value > 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_rw must be 0..4");
+        if (value != 0 && value != 1 && value != 2 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mkg_rw must be 0 (by batch size), 1, 2 or 4 (4: the two-wave 4- / 8-party kernel only)");
         c->mkg_rw = (int)value;
         return TFHE_OK;
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B kernel timing in ONE process (interleaved rounds): tools/ab_bench.py --variants 1 2 3 --rounds 5
+"""A/B kernel timing in ONE process (interleaved rounds): tools/ab_bench.py --option v3_rw --variants 1 4 --rounds 5
 Reports the blind-rotate and keyswitch kernel durations (HIP events) per variant, median and min, and
 checks every variant's output against variant-independent expectations (decrypts to NAND; all equal)."""
 import argparse, json, os, sys
@@ -12,7 +12,7 @@ ap.add_argument("--variants", type=int, nargs="+", default=[1, 2])
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--gates", type=int, default=4096)
 ap.add_argument("--params", default="80")
-ap.add_argument("--option", default="br_variant")
+ap.add_argument("--option", default="v3_rw")
 args = ap.parse_args()
 
 params = tfhe.tfhe_parameters_80() if args.params == "80" else tfhe.tfhe_parameters_128()
