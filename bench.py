@@ -464,8 +464,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "frac_of_measured_copy_rate": achieved / 6.29e12,      # 6.29 TB/s float4 copy (MI355X_MICROARCH.md), quoted beside the 8 TB/s spec
+                # PMC counters cannot be read from inside a run: `traffic` is REPLAYED from the committed rocprofv3 profile named in
+                # traffic_replayed_from (same kernel sources by hash, same launch shape), or null — see profile_counters()
                 "traffic": prof.get("hbm_bytes_per_launch"),
-                "traffic_source": prof.get("source"),
+                "traffic_is_replayed": prof.get("hbm_bytes_per_launch") is not None,
+                "traffic_replayed_from": prof.get("source"),
                 "counters_note": prof.get("note"),
                 "bytes_per_unit": br_bytes(params),
                 "units_per_launch": rotations_per_step,
@@ -484,9 +487,9 @@ def main():
                 "clock_mhz": clock_mhz,
                 "clock_source": "s_memtime / s_memrealtime inside the DIAG instantiation of the same kernel after >= 2 s of back-to-back launches" if clock_mhz else None,
                 "frac_at_measured_clock": (flops / (FP64_VALU_PEAK * clock_mhz / MAX_CLOCK_MHZ)) if clock_mhz else None,
-                "valu_busy_frac": prof.get("valu_busy_frac"),
-                "valu_insts_per_launch": prof.get("valu_insts_per_launch"),
-                "counters_source": prof.get("source"),
+                "valu_busy_frac_replayed": prof.get("valu_busy_frac"),
+                "valu_insts_per_launch_replayed": prof.get("valu_insts_per_launch"),
+                "counters_replayed_from": prof.get("source"),
                 "rounding_margin": margin,
             },
         }

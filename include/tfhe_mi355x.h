@@ -263,7 +263,10 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
 
 /* The same timing of up to the last 32 batch calls on a one-device ctx, oldest first, read in ONE go after the calls: a
  * caller timing a sequence of asynchronous calls need not synchronise (and so serialise its host work with the device)
- * after each one.  ms: room for max_calls floats; *n_out = entries written (<= max_calls, <= 32, <= calls made). */
+ * after each one.  ms: room for max_calls floats; *n_out = entries written (<= max_calls, <= 32, <= calls made).  A call
+ * that failed part-way is not counted.  The history is per stream: after tfhe_gates_batch_submit it holds the batches that
+ * took the context's own stream (every other one); a blocking host-buffer call that ran as two halves contributes the half
+ * on the own stream (tfhe_last_timing_ms spans both). */
 int32_t tfhe_timing_history_ms(tfhe_ctx *ctx, int32_t which, float *ms, int32_t max_calls, int32_t *n_out);
 
 /* Number of blind rotations the most recent batch call executed (MUX counts 2). */

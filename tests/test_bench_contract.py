@@ -30,7 +30,7 @@ def test_bench_json_line_is_consistent():
     assert abs(d["value"] - 512 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert 0.1 < d["ms_per_bootstrap_single_gate"] < 50
     # the kernel named is the one the engine launched for this batch size (512 rotations: the two-wave kernel)
-    assert rf["kernel"] == "blind_rotate_kernel_w2<2,rw2>" and "bound_note" in rf and "traffic_source" in rf
+    assert rf["kernel"] == "blind_rotate_kernel_w2<2,rw2>" and "bound_note" in rf and "traffic_replayed_from" in rf and "traffic_is_replayed" in rf
     r2 = d["roofline_secondary"]
     assert r2["bound"] == "fp64_valu" and r2["kernel"] == rf["kernel"] and r2["flops_per_unit"] == 500 * (6 * 5 * 512 * 9 + 8 * 512 * 8)
     assert abs(r2["achieved"] - 512 * r2["flops_per_unit"] / (rf["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r2["achieved"]

@@ -180,9 +180,15 @@ def test_device_keygen_on_a_multi_device_context(tfhe):
     rng = np.random.default_rng(5)
     sk = tfhe.SecretKey(rng, p)
     st = rng.bit_generator.state
-    ck1 = tfhe.CloudKey(rng, sk, keygen="device", device=0)
+    fixed = [11, 22, 33, 44]                 # (the noise key otherwise comes from os.urandom, whatever `rng` is)
+    ck1 = tfhe.CloudKey(rng, sk, keygen="device", device=0, noise_seed=fixed)
     rng.bit_generator.state = st
-    ck2 = tfhe.CloudKey(rng, sk, keygen="device", device=[0, 0])
+    ck2 = tfhe.CloudKey(rng, sk, keygen="device", device=[0, 0], noise_seed=fixed)
+    rng.bit_generator.state = st
+    ck3 = tfhe.CloudKey(rng, sk, keygen="device", device=0)
+    assert not np.array_equal(ck1.bootstrap_key, ck3.bootstrap_key)               # a fresh noise key from the OS every time
+    assert np.array_equal(ck1.bootstrap_key[..., 0, :], ck3.bootstrap_key[..., 0, :])   # ... under the same (public, rng-drawn) masks
+    ck3.close()
     assert not hasattr(ck1, "keygen_seed") and sk.cloud_keygen_seed is not None      # the seed stays on the secret side
     assert np.array_equal(ck1.bootstrap_key, ck2.bootstrap_key) and np.array_equal(ck1.keyswitch_key, ck2.keyswitch_key)
     bits = rng.integers(0, 2, (2, 40)).astype(bool)

@@ -11,7 +11,10 @@
 //   seed[2..5]  128 bits that are AS SECRET AS THE SECRET KEY: they key the NOISE streams 2 and 4 (Philox key =
 //               seed[2..3], counter words 2 and 3 = stream ^ seed[4], seed[5]).  Whoever knows them can subtract every
 //               noise term and solve b - e = <a, s> for the secret keys; and because they are independent of the mask
-//               key, the public mask words give no handle for guessing them.
+//               key, the public mask words give no handle for guessing them.  Philox is a statistical generator with no
+//               PRF security claim: it is used here as a NON-CRYPTOGRAPHIC EXPANDER of that 128-bit secret, which the
+//               caller must draw from a cryptographic source (the shipped wrappers take it from os.urandom /
+//               RandomDevice() whatever generator they were handed; tests pass fixed words).
 //   stream 1: bootstrap-key mask words      index = ((sample * k) + c) * N + coefficient
 //   stream 2: bootstrap-key noise           index = sample * N + coefficient
 //   stream 3: keyswitch-key mask words      index = sample * n + m
@@ -107,13 +110,16 @@ __global__ __launch_bounds__(256) void bk_kernel(Args A)
         for (int c = 0; c < k; c++) {
             const uint32_t *a = a_lds + c * N;
             for (int w0 = 0; w0 < N / 32; w0++) {
-                uint32_t bits = s_bits[c * (N / 32) + w0];
-                while (bits) {
-                    const int m = w0 * 32 + __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    const int idx = co - m;                               // X^m * a: coefficient co takes a[co - m], negated on wrap
+                // Every bit position is visited and its term masked in or out: the trip count, the LDS addresses and the
+                // instruction stream do not depend on the secret key bits (a `while (bits)` loop over the set bits would
+                // make the kernel's duration a function of the key's Hamming weight per word).
+                const uint32_t bits = s_bits[c * (N / 32) + w0];
+#pragma unroll 8
+                for (int b = 0; b < 32; b++) {
+                    const int idx = co - (w0 * 32 + b);                   // X^m * a: coefficient co takes a[co - m], negated on wrap
                     const uint32_t v = a[idx & (N - 1)];
-                    acc += idx < 0 ? 0u - v : v;
+                    const uint32_t take = 0u - ((bits >> b) & 1u);        // all ones where key bit m is set
+                    acc += (idx < 0 ? 0u - v : v) & take;
                 }
             }
         }

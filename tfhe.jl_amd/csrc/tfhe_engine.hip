@@ -395,8 +395,16 @@ static int32_t fan_out(tfhe_ctx *c, const std::vector<int> &which, F &&fn)
 {
     std::vector<int32_t> rcs(which.size(), TFHE_OK);
     std::vector<std::thread> th;
-    for (size_t i = 1; i < which.size(); i++) th.emplace_back([&, i] { rcs[i] = fn(which[i]); });
+    std::vector<size_t> inline_ones;          // kids whose thread could not be started (thread / process limit): run here, in turn
+    for (size_t i = 1; i < which.size(); i++) {
+        try {
+            th.emplace_back([&, i] { rcs[i] = fn(which[i]); });
+        } catch (const std::exception &) {    // no exception may cross the C ABI
+            inline_ones.push_back(i);
+        }
+    }
     if (!which.empty()) rcs[0] = fn(which[0]);
+    for (size_t i : inline_ones) rcs[i] = fn(which[i]);
     for (auto &t : th) t.join();
     std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
     for (int k : which) c->kid_ran[(size_t)k] = 1;
@@ -449,6 +457,12 @@ static void quiesce(tfhe_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->twin && c->twin->stream) (void)hipStreamSynchronize(c->twin->stream);
     c->slot_busy[0] = c->slot_busy[1] = false;
+    if (c->twin) {
+        // every caller of quiesce is about to free or replace key buffers: the twin borrows them, so it must not keep the old
+        // addresses (ensure_twin re-points it at the owner's current keys before its next use)
+        tfhe_ctx *t = c->twin;
+        t->d_bk = nullptr; t->d_ks = nullptr; t->d_ksp = nullptr; t->d_ks4 = nullptr; t->have_bk = false; t->have_ks = false;
+    }
 }
 
 static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
@@ -949,12 +963,19 @@ static int32_t leave_stream(tfhe_ctx *c, hipStream_t s)
     return TFHE_OK;
 }
 
-// every batch call records its four timing events into the next slot of the ring
+// Every batch call records its four timing events into the next slot of the ring.  The slot is TAKEN at the start of a call
+// and COUNTED only once its fourth event has been recorded (commit_timing_slot): a call that fails between the two leaves
+// timed_calls alone, the next call reuses the slot, and tfhe_timing_history_ms never sees a half-recorded set.
 static void next_timing_slot(tfhe_ctx *c)
 {
     c->ev = c->evring[c->timed_calls % tfhe_ctx::kTimingSlots];
-    c->timed_calls++;
+    c->timing_valid = false;
     c->last_call_two_streams = false;
+}
+static void commit_timing_slot(tfhe_ctx *c)
+{
+    c->timed_calls++;
+    c->timing_valid = true;
 }
 
 static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
@@ -1065,7 +1086,7 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
         hipLaunchKernelGGL(trivial_gates_kernel, dim3((unsigned)Tn), dim3(256), 0, s, d_in0, d_ts, d_td, d_top, d_out, n);
         HIP_TRY(c, hipGetLastError());
     }
-    c->timing_valid = true;
+    commit_timing_slot(c);
     c->last_rotations = (int64_t)R;
     return leave_stream(c, s);
 }
@@ -1207,7 +1228,8 @@ static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const
                                       int32_t *out, int64_t B, const bool (&need)[3]);
 
 // The twin of a one-device context: same device, its own stream / workspaces / events, the OWNER's keys (read-only on the
-// device).  Made on first use, dropped whenever the owner's keys are reloaded; the owner's tunables are copied at every use.
+// device).  Made on first use and kept; a key reload synchronises it and clears its borrowed pointers (quiesce), and every
+// use re-points it at the owner's current keys and copies the owner's tunables.
 static int32_t ensure_twin(tfhe_ctx *c)
 {
     if (!c->twin) {
@@ -1275,7 +1297,14 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
             auto off = [&](const int32_t *p, int64_t g) { return p ? p + (size_t)g * n1 : nullptr; };
             const int64_t h = bounds[1];
             int32_t rc1 = TFHE_OK;
-            std::thread second([&] { rc1 = gates_batch_one_stream(c->twin, opcodes + h, off(in0, h), off(in1, h), off(in2, h), out + (size_t)h * n1, B - h, need); });
+            // (std::thread's constructor throws std::system_error when the process may not start another thread — a thread or
+            //  process limit: no exception may cross the C ABI, so the batch then simply runs on one stream)
+            std::thread second;
+            try {
+                second = std::thread([&] { rc1 = gates_batch_one_stream(c->twin, opcodes + h, off(in0, h), off(in1, h), off(in2, h), out + (size_t)h * n1, B - h, need); });
+            } catch (const std::exception &) {
+                return gates_batch_one_stream(c, opcodes, in0, in1, in2, out, B, need);
+            }
             const int32_t rc0 = gates_batch_one_stream(c, opcodes, in0, in1, in2, out, h, need);
             second.join();
             if (rc1) return c->set_err(rc1, "gates_batch (second half): %s", c->twin->err.c_str());
@@ -1351,6 +1380,7 @@ int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32
     }
     const int32_t rc = gates_batch_enqueue(t, opcodes, in0, in1, in2, out, B, need);
     if (rc) return slot ? c->set_err(rc, "gates_batch_submit: %s", t->err.c_str()) : rc;
+    if (slot) { c->last_rotations = t->last_rotations; c->last_kernel = t->last_kernel; }     // tfhe_last_rotation_count / _kernel_name describe the newest submit, whichever stream took it
     c->submits++;
     c->slot_busy[slot] = true;
     *ticket = slot;
@@ -1364,7 +1394,7 @@ int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket)
     if (ticket != 0 && ticket != 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_wait: ticket %d was not issued by tfhe_gates_batch_submit", ticket);
     if (!c->slot_busy[ticket]) return TFHE_OK;     // already waited for (or displaced by a later submit, which waited)
     tfhe_ctx *t = ticket ? c->twin : c;
-    if (!t) return c->set_err(TFHE_ERR_STATE, "gates_batch_wait: the second stream's context is gone (keys reloaded while a batch was in flight)");
+    if (!t) return c->set_err(TFHE_ERR_STATE, "gates_batch_wait: ticket 1 was never issued (no batch has used the second stream)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(t->stream));
     c->slot_busy[ticket] = false;
@@ -1419,7 +1449,7 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
     rc = leave_stream(c, s);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->timing_valid = true;
+    commit_timing_slot(c);
     c->last_rotations = B;
     return TFHE_OK;
 }
@@ -1459,7 +1489,7 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     rc = leave_stream(c, s);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->timing_valid = true;
+    commit_timing_slot(c);
     c->last_rotations = 0;
     c->diag_rows = 0;
     return TFHE_OK;
@@ -1812,7 +1842,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     rc = leave_stream(c, s);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(s));
-    c->timing_valid = true;
+    commit_timing_slot(c);
     c->last_rotations = B;
     return TFHE_OK;
 }
@@ -1870,7 +1900,7 @@ int32_t tfhe_timing_history_ms(tfhe_ctx *c, int32_t which, float *ms, int32_t ma
     const int32_t n = (int32_t)std::min<int64_t>(have, max_calls);
     if (n == 0) return TFHE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventSynchronize(c->ev[3]));          // the newest call has finished: so have the older ones on this context
+    HIP_TRY(c, hipEventSynchronize(c->evring[(c->timed_calls - 1) % tfhe_ctx::kTimingSlots][3]));   // the newest complete call has finished: so have the older ones on this context
     for (int32_t i = 0; i < n; i++) {                   // oldest of the n first
         hipEvent_t *set = c->evring[(c->timed_calls - n + i) % tfhe_ctx::kTimingSlots];
         HIP_TRY(c, hipEventElapsedTime(ms + i, set[a], set[b]));

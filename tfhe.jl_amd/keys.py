@@ -6,6 +6,8 @@ CloudKey keeps the flat arrays the C ABI takes (include/tfhe_mi355x.h) and uploa
 device context on first use.  The random stream is numpy's (PCG64), not Julia's MersenneTwister:
 keys are data that crosses the boundary, the hot path itself consumes no randomness.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -82,18 +84,26 @@ class SecretKey:
 class CloudKey:
     """api.jl:111-127.  Holds the flat key arrays; `engine(device)` gives the device context."""
 
-    def __init__(self, rng, secret_key: SecretKey, keygen="host", device=0):
-        """keygen="host": numpy (the reference does this work on the host too); keygen="device": the TLWE key bits and a
-        seed of six 32-bit words (two for the public masks, four — 128 bits — for the noise) are drawn from `rng`, the key
-        material is generated on GPU `device` (tfhe_keygen_cloud_key) and the context that made it stays loaded as
-        `engine(device)`.  The seed is as secret as the secret key (it regenerates every noise term): it is kept on the
-        SecretKey object, never on this (public) one.  For real keys `rng` must be a cryptographic generator."""
+    def __init__(self, rng, secret_key: SecretKey, keygen="host", device=0, noise_seed=None):
+        """keygen="host": numpy (the reference does this work on the host too); keygen="device": the key material is
+        generated on GPU `device` (tfhe_keygen_cloud_key) and the context that made it stays loaded as `engine(device)`.
+        The TLWE key bits and the two seed words that key the PUBLIC mask streams come from `rng`; the four words (128
+        bits) that key the NOISE streams come from the operating system's generator (os.urandom) whatever `rng` is —
+        numpy's generators are statistical, not cryptographic, and Philox, which the library expands this secret with, makes
+        no secrecy claim of its own.  `noise_seed` (four 32-bit words) overrides that for reproducible tests.  The seed is as
+        secret as the secret key (it regenerates every noise term): it is kept on the SecretKey object, never on this
+        (public) one."""
         p = secret_key.params
         self.params = p
         self._engines = {}
         tlwe_key = TLweKey(rng, p.tlwe_polynomial_degree, p.tlwe_mask_size)
         if keygen == "device":
-            seed = rng.integers(0, 2**32, 6, dtype=np.uint64).astype(np.uint32)
+            mask_words = rng.integers(0, 2**32, 2, dtype=np.uint64).astype(np.uint32)
+            noise_words = (np.frombuffer(os.urandom(16), dtype=np.uint32) if noise_seed is None
+                           else np.ascontiguousarray(noise_seed, dtype=np.uint32).reshape(-1))
+            if noise_words.size != 4:
+                raise ValueError("noise_seed must be four 32-bit words")
+            seed = np.concatenate([mask_words, noise_words]).astype(np.uint32)
             e = _lib.Engine(p, device) if np.ndim(device) == 0 else _lib.Engine(p, devices=[int(d) for d in device])
             try:
                 self.bootstrap_key, self.keyswitch_key = e.keygen_cloud_key(secret_key.key.key, tlwe_key.key, p.bs_noise_stddev,
@@ -131,12 +141,12 @@ class CloudKey:
         self._engines = {}
 
 
-def make_key_pair(rng, params: SchemeParameters = None, keygen="host", device=0):
+def make_key_pair(rng, params: SchemeParameters = None, keygen="host", device=0, noise_seed=None):
     """api.jl:139-146 (keygen="device": the cloud key is generated on the GPU, see CloudKey)"""
     if params is None:
         params = tfhe_parameters_80()
     secret_key = SecretKey(rng, params)
-    cloud_key = CloudKey(rng, secret_key, keygen=keygen, device=device)
+    cloud_key = CloudKey(rng, secret_key, keygen=keygen, device=device, noise_seed=noise_seed)
     return secret_key, cloud_key
 
 
