@@ -113,8 +113,11 @@ void tfhe_ctx_destroy(tfhe_ctx *ctx);
  * tfhe_bootstrap_batch, tfhe_keyswitch_batch and tfhe_mk_gate_nand_batch split the batch into contiguous shards
  * (gates: balanced by blind-rotation count, MUX = 2) that run concurrently and write into the caller's buffers.
  * There is no communication between devices: the gates of a batch are independent (gates.jl).
- * tfhe_gates_batch_dev needs n_dev == 1 (a device pointer belongs to one device); the wire-table entry points
- * (tfhe_wires_*, tfhe_gates_level) run on the first device.  Results are bit-identical to a one-device context. */
+ * tfhe_gates_batch_dev needs n_dev == 1 (a device pointer belongs to one device).  tfhe_gates_batch_submit gives every
+ * device its shard as a submit of its own, so each keeps two batches in flight.  The wire table (tfhe_wires_*) is
+ * replicated on every device; tfhe_gates_level runs a level of fewer than "level_split_min" blind rotations (option,
+ * default 4096) on the first device and shards a wider one over all of them, exchanging the written wires through host
+ * memory afterwards (no peer access is assumed).  Results are bit-identical to a one-device context. */
 int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_ids, int32_t n_dev,
                               tfhe_ctx **out_ctx);
 /* Number of device contexts behind ctx (1 for tfhe_ctx_create). */

@@ -78,3 +78,60 @@ def test_log_depth_minimum_circuit_on_device(tfhe, orc, keys80):
         res = c.run(K.ck, enc)
         assert sum(int(v) << i for i, v in enumerate(tfhe.decrypt(K.sk, res))) == min(a, b), (a, b)
     assert np.array_equal(res.data, _oracle_eval(c, K.oracle, orc, enc.data))
+
+
+@pytest.mark.gpu
+def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
+    """A multi-device context ({0, 0} on the one-GPU box: two device contexts, two replicas of the wire table) runs narrow
+    levels on its first device and shards wide ones (option level_split_min, lowered here so that the 17- and 16-gate levels
+    of the tutorial circuit split), exchanging the written wires through host memory: same words as one device, for the
+    reference's circuit (examples/tutorial.jl:42-62) and for the log-depth variant whose wide levels feed narrow ones."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from tutorial import encrypted_minimum_circuit
+    K = keys80
+    bits = [(2017 >> i) & 1 == 1 for i in range(16)] + [(42 >> i) & 1 == 1 for i in range(16)]
+    enc = tfhe.encrypt(K.rng, K.sk, bits)
+    multi = K.ck.engine([0, 0])
+    for circ in (tutorial_min_circuit(tfhe, 16), encrypted_minimum_circuit(16, log_depth=True)):
+        want = circ.run(K.ck, enc).data
+        for split in (4096, 8, 2):            # never split at these sizes / only the 16-gate levels / everything but single gates
+            multi.set_option("level_split_min", split)
+            got = circ.run(K.ck, enc, device=[0, 0]).data
+            assert np.array_equal(got, want), split
+    # intermediate wires are coherent too: every wire of the table, read back from the first device
+    circ = tutorial_min_circuit(tfhe, 16)
+    multi.set_option("level_split_min", 8)
+    circ.run(K.ck, enc, device=[0, 0])
+    all_multi = multi.wires_gather(np.arange(circ.num_wires, dtype=np.int32))
+    circ.run(K.ck, enc)
+    assert np.array_equal(all_multi, K.ck.engine(0).wires_gather(np.arange(circ.num_wires, dtype=np.int32)))
+    multi.set_option("level_split_min", 4096)
+
+
+@pytest.mark.gpu
+def test_streamed_batches_on_a_multi_device_context(tfhe, keys80, orc):
+    """tfhe_gates_batch_submit / _wait on a multi-device context: every device takes its shard as a submit of its own (two
+    batches in flight per device); results equal the blocking call's and the oracle's on a sample."""
+    K = keys80
+    multi = K.ck.engine([0, 0])
+    rng = np.random.default_rng(31)
+    names = ["NAND", "AND", "OR", "XOR", "MUX"]
+    jobs = []
+    for B in (600, 64, 3, 900):
+        ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, 5, B)], np.uint8)
+        ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+        jobs.append((ops, ins, multi.gates(ops, *ins)))
+    idx = [0, 1, 2]
+    assert np.array_equal(jobs[0][2][idx], K.oracle.gates(jobs[0][0][idx], *[a[idx] for a in jobs[0][1]], nthreads=3))
+    tickets, outs = [], []
+    for ops, ins, _ in jobs:                  # four submits: the third displaces (waits for) the first
+        pin = [tfhe.pinned_empty(a.shape) for a in ins]
+        for p, a in zip(pin, ins):
+            p[:] = a
+        t, o = multi.gates_submit(ops, *pin)
+        tickets.append(t); outs.append(o)
+    for t in tickets:
+        multi.gates_wait(t)
+    for (ops, ins, want), got in zip(jobs, outs):
+        assert np.array_equal(got, want)

@@ -134,6 +134,9 @@ struct tfhe_ctx {
     bool borrows_keys = false;
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
     uint32_t submits = 0;
+    std::vector<uint8_t> wire_stale;      // multi-device context: wires whose current value is on the first device only (written by a level that ran there)
+    int64_t level_split_min = 4096;       // multi-device context: levels of at least this many blind rotations are sharded over the devices (tfhe_set_option("level_split_min", n); < 0: never)
+    std::vector<int32_t> kid_tickets[2];  // multi-device context: per submit slot, the ticket every kid gave for its shard (2: none)
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
@@ -385,6 +388,12 @@ __global__ void gather_rows_kernel(const int32_t *__restrict__ table, const int3
 {
     const size_t src = (size_t)idx[blockIdx.x], dst = blockIdx.x;
     for (int i = threadIdx.x; i < n1; i += blockDim.x) out[dst * n1 + i] = table[src * n1 + i];
+}
+
+__global__ void scatter_rows_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ idx, int32_t *__restrict__ table, int n1)
+{
+    const size_t src = blockIdx.x, dst = (size_t)idx[blockIdx.x];
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) table[dst * n1 + i] = rows[src * n1 + i];
 }
 
 // ---- fan-out helpers --------------------------------------------------------------------------------
@@ -1112,12 +1121,16 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t 
 }
 
 // ---- levelised circuit execution on a device-resident wire table -------------------------
-// On a multi-device context the wire table lives on the first device (a level's gates exchange wires with every
-// other level, so sharding them would need a peer copy per level).
+// On a multi-device context every device holds a replica of the wire table; multi_gates_level keeps the replicas coherent
+// (narrow levels on the first device, wide levels sharded, written wires exchanged through host memory).
 int32_t tfhe_wires_alloc(tfhe_ctx *c, int64_t num_wires)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) { const int32_t rc = tfhe_wires_alloc(c->kids[0], num_wires); if (rc) c->err = c->kids[0]->err; return rc; }
+    if (c->multi()) {      // one replica of the table per device (multi_gates_level keeps them coherent)
+        const int32_t rc = fan_out(c, all_kids(c), [&](int k) { return tfhe_wires_alloc(c->kids[(size_t)k], num_wires); });
+        if (rc == TFHE_OK) { c->num_wires = num_wires; c->wire_stale.assign((size_t)std::max<int64_t>(num_wires, 0), 0); }
+        return rc;
+    }
     if (num_wires < 0 || num_wires > ((int64_t)1 << 30)) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_alloc: bad wire count");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1140,7 +1153,11 @@ static int32_t wires_range_ok(tfhe_ctx *c, const char *who, int64_t first, int64
 int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32_t *host)
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) { const int32_t rc = tfhe_wires_upload(c->kids[0], first, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
+    if (c->multi()) {
+        const int32_t rc = fan_out(c, all_kids(c), [&](int k) { return tfhe_wires_upload(c->kids[(size_t)k], first, count, host); });
+        if (rc == TFHE_OK) std::fill(c->wire_stale.begin() + first, c->wire_stale.begin() + first + count, 0);
+        return rc;
+    }
     int32_t rc = wires_range_ok(c, "wires_upload", first, count, host);
     if (rc || count == 0) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1190,20 +1207,35 @@ int32_t tfhe_wires_gather(tfhe_ctx *c, const int32_t *wires, int64_t count, int3
     return TFHE_OK;
 }
 
-int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
-                         const int32_t *out, int64_t B)
+// rows `host` [count][n+1] -> wires[] of this device's table (the inverse of tfhe_wires_gather; internal)
+static int32_t wires_scatter(tfhe_ctx *c, const int32_t *wires, int64_t count, const int32_t *host)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) { const int32_t rc = tfhe_gates_level(c->kids[0], opcodes, a, b, cc, out, B); if (rc) c->err = c->kids[0]->err; c->kid_ran[0] = 1; return rc; }
-    if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: NULL argument or negative B");
-    if (B == 0) return TFHE_OK;
-    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_level: context is multi-key");
-    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "gates_level: no wire table allocated");
-    // every index in range; no wire both written and read inside one level (the level's gates are independent).
-    // O(B) work whatever the size of the wire table: only the level's own output wires are hashed.
+    if (count == 0) return TFHE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
+    const int n1 = c->P.n + 1;
+    int32_t rc = ensure_host_map(c, (size_t)count * 4);
+    if (rc) return rc;
+    memcpy(c->h_map, wires, (size_t)count * 4);
+    HIP_TRY(c, c->map.reserve((size_t)count * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, c->io[3].reserve((size_t)count * n1 * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->io[3].p, host, (size_t)count * n1 * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)count), dim3(256), 0, s, (const int32_t *)c->io[3].p, (const int32_t *)c->map.p, c->d_wires, n1);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return TFHE_OK;
+}
+
+// every index in range; no wire both written and read inside one level (the level's gates are independent).
+// O(B) work whatever the size of the wire table: only the level's own output wires are hashed.
+static int32_t validate_level(tfhe_ctx *c, int64_t num_wires, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
+                              const int32_t *out, int64_t B)
+{
     std::unordered_set<int32_t> written;
     written.reserve((size_t)B * 2);
-    auto bad = [&](int64_t v) { return v < 0 || v >= c->num_wires; };
+    auto bad = [&](int64_t v) { return v < 0 || v >= num_wires; };
     for (int64_t g = 0; g < B; g++) {
         const int op = opcodes[g];
         if (op >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: bad opcode %d at gate %lld", op, (long long)g);
@@ -1217,6 +1249,96 @@ int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, 
         if ((op_has_a(op) && written.count(a[g])) || (op_has_b(op) && written.count(b[g])) || (op == TFHE_GATE_MUX && written.count(cc[g])))
             return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: gate %lld reads a wire written in the same level", (long long)g);
     }
+    return TFHE_OK;
+}
+
+// One level on a multi-device context.  Every device holds a replica of the wire table.  A level of fewer than
+// level_split_min blind rotations runs on the first device only (a level costs one blind-rotation latency however few
+// gates it has: spreading a narrow one buys nothing) and its outputs are marked stale on the others; a wide level — the
+// 16 parallel MUXes of examples/tutorial.jl:60 are the small case — first brings the stale wires it reads up to date
+// everywhere, is then cut into rotation-balanced contiguous shards that run concurrently, and finally every device
+// receives the rows the others wrote (host-staged: gather to a host block, scatter from it; no peer access is assumed).
+static int32_t multi_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
+                                 const int32_t *out, int64_t B)
+{
+    const int nk = (int)c->kids.size();
+    int32_t rc = validate_level(c, c->num_wires, opcodes, a, b, cc, out, B);
+    if (rc) return rc;
+    int64_t R = 0;
+    for (int64_t g = 0; g < B; g++) R += opcodes[g] == TFHE_GATE_MUX ? 2 : op_has_b(opcodes[g]) ? 1 : 0;
+    std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
+    if (nk == 1 || c->level_split_min < 0 || R < c->level_split_min) {
+        rc = tfhe_gates_level(c->kids[0], opcodes, a, b, cc, out, B);
+        if (rc) c->err = c->kids[0]->err;
+        c->kid_ran[0] = 1;
+        if (rc == TFHE_OK && nk > 1) for (int64_t g = 0; g < B; g++) c->wire_stale[(size_t)out[g]] = 1;
+        return rc;
+    }
+    const size_t n1 = (size_t)c->P.n + 1;
+    // 1. stale operands: first device -> host -> the others
+    std::vector<int32_t> need;
+    for (int64_t g = 0; g < B; g++) {
+        const int op = opcodes[g];
+        const int32_t src[3] = {op_has_a(op) ? a[g] : -1, op_has_b(op) ? b[g] : -1, op == TFHE_GATE_MUX ? cc[g] : -1};
+        for (int32_t w : src)
+            if (w >= 0 && c->wire_stale[(size_t)w]) { c->wire_stale[(size_t)w] = 0; need.push_back(w); }
+    }
+    std::vector<int32_t> stage;
+    if (!need.empty()) {
+        stage.resize(need.size() * n1);
+        rc = tfhe_wires_gather(c->kids[0], need.data(), (int64_t)need.size(), stage.data());
+        if (rc) { c->err = c->kids[0]->err; return rc; }
+        std::vector<int> others;
+        for (int k = 1; k < nk; k++) others.push_back(k);
+        rc = fan_out(c, others, [&](int k) { return wires_scatter(c->kids[(size_t)k], need.data(), (int64_t)need.size(), stage.data()); });
+        if (rc) return rc;
+    }
+    // 2. the shards, concurrently
+    std::vector<int64_t> bounds((size_t)nk + 1);
+    shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
+    std::vector<int> which;
+    for (int r = 0; r < nk; r++)
+        if (bounds[(size_t)r + 1] > bounds[(size_t)r]) which.push_back(r);
+    auto off = [&](const int32_t *p, int64_t g) { return p ? p + g : nullptr; };
+    rc = fan_out(c, which, [&](int r) {
+        const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
+        return tfhe_gates_level(c->kids[(size_t)r], opcodes + s0, off(a, s0), off(b, s0), off(cc, s0), out + s0, cnt);
+    });
+    if (rc) return rc;
+    // 3. all-gather of the written rows through one host block: every shard's device reads its rows out, every device
+    //    takes in what the others wrote (its own shard is the contiguous range [s0, e0) of the block)
+    stage.resize((size_t)B * n1);
+    rc = fan_out(c, which, [&](int r) {
+        const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
+        return tfhe_wires_gather(c->kids[(size_t)r], out + s0, cnt, stage.data() + (size_t)s0 * n1);
+    });
+    if (rc) return rc;
+    rc = fan_out(c, all_kids(c), [&](int k) {
+        const int64_t s0 = bounds[(size_t)k], e0 = bounds[(size_t)k + 1];
+        int32_t r1 = wires_scatter(c->kids[(size_t)k], out, s0, stage.data());
+        if (r1) return r1;
+        return wires_scatter(c->kids[(size_t)k], out + e0, B - e0, stage.data() + (size_t)e0 * n1);
+    });
+    if (rc) return rc;
+    for (int64_t g = 0; g < B; g++) c->wire_stale[(size_t)out[g]] = 0;
+    std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);            // timing / rotation queries describe the shards that computed
+    for (int r : which) c->kid_ran[(size_t)r] = 1;
+    return TFHE_OK;
+}
+
+int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
+                         const int32_t *out, int64_t B)
+{
+    if (!c) return TFHE_ERR_INVALID_ARG;
+    if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: NULL argument or negative B");
+    if (B == 0) return TFHE_OK;
+    if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "gates_level: context is multi-key");
+    if (c->multi()) {
+        if (c->num_wires <= 0) return c->set_err(TFHE_ERR_STATE, "gates_level: no wire table allocated");
+        return multi_gates_level(c, opcodes, a, b, cc, out, B);
+    }
+    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "gates_level: no wire table allocated");
+    { const int32_t rcv = validate_level(c, c->num_wires, opcodes, a, b, cc, out, B); if (rcv) return rcv; }
     HIP_TRY(c, hipSetDevice(c->device));
     // run_gates substitutes row 0 for operands an opcode does not read; a NULL index array (never read, checked above)
     // is replaced by `out` only so that the pointer is non-NULL
@@ -1359,7 +1481,38 @@ int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32
     *ticket = 2;                                   // "complete": nothing to wait for
     if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
-    // contexts that cannot run two batches side by side (several devices, multi-key, diagnostics, a borrowed key) run this one now
+    if (c->multi() && c->P.parties == 1) {
+        // every device takes its rotation-balanced shard as a submit of its own (enqueued from this thread, one device after
+        // the other: nothing is waited for), so each device keeps two batches in flight exactly as a one-device context does
+        const int nk = (int)c->kids.size();
+        for (int64_t g = 0; g < B; g++)
+            if (opcodes[g] >= TFHE_GATE__COUNT) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: bad opcode %d at gate %lld", opcodes[g], (long long)g);
+        const int slot = (int)(c->submits & 1u);
+        if (c->slot_busy[slot]) { const int32_t rcw = tfhe_gates_batch_wait(c, slot); if (rcw) return rcw; }
+        std::vector<int64_t> bounds((size_t)nk + 1);
+        shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
+        const size_t n1 = (size_t)c->P.n + 1;
+        c->kid_tickets[slot].assign((size_t)nk, 2);
+        std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
+        for (int r = 0; r < nk; r++) {
+            const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
+            if (cnt <= 0) continue;
+            auto off = [&](const int32_t *p) { return p ? p + (size_t)s0 * n1 : nullptr; };
+            const int32_t rc = tfhe_gates_batch_submit(c->kids[(size_t)r], opcodes + s0, off(in0), off(in1), off(in2), out + (size_t)s0 * n1, cnt, &c->kid_tickets[slot][(size_t)r]);
+            c->kid_ran[(size_t)r] = 1;
+            if (rc) {
+                c->set_err(rc, "device %d (kid %d): %s", c->kids[(size_t)r]->device, r, c->kids[(size_t)r]->err.c_str());
+                c->slot_busy[slot] = true;                  // what the earlier kids took is waited for before the error is returned
+                (void)tfhe_gates_batch_wait(c, slot);
+                return rc;
+            }
+        }
+        c->submits++;
+        c->slot_busy[slot] = true;
+        *ticket = slot;
+        return TFHE_OK;
+    }
+    // contexts that cannot run two batches side by side (multi-key, diagnostics, a borrowed key) run this one now
     if (c->multi() || c->P.parties != 1 || c->measure_margin || c->borrows_keys || !c->have_bk || !c->have_ks)
         return tfhe_gates_batch(c, opcodes, in0, in1, in2, out, B);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1393,6 +1546,15 @@ int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket)
     if (ticket == 2) return TFHE_OK;
     if (ticket != 0 && ticket != 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_wait: ticket %d was not issued by tfhe_gates_batch_submit", ticket);
     if (!c->slot_busy[ticket]) return TFHE_OK;     // already waited for (or displaced by a later submit, which waited)
+    if (c->multi()) {
+        int32_t first_rc = TFHE_OK;
+        for (size_t r = 0; r < c->kids.size() && r < c->kid_tickets[ticket].size(); r++) {
+            const int32_t rc = tfhe_gates_batch_wait(c->kids[r], c->kid_tickets[ticket][r]);
+            if (rc && !first_rc) { first_rc = rc; c->set_err(rc, "device %d (kid %d): %s", c->kids[r]->device, (int)r, c->kids[r]->err.c_str()); }
+        }
+        c->slot_busy[ticket] = false;
+        return first_rc;
+    }
     tfhe_ctx *t = ticket ? c->twin : c;
     if (!t) return c->set_err(TFHE_ERR_STATE, "gates_batch_wait: ticket 1 was never issued (no batch has used the second stream)");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2043,6 +2205,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
+    if (!strcmp(name, "level_split_min")) { c->level_split_min = value; return TFHE_OK; }
     if (!strcmp(name, "br_prio_pct")) {
         if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
         c->br_prio_pct = (int)value;
