@@ -290,8 +290,8 @@ int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
  * ticks x 100 MHz around the kernel body, median over workgroups (what FP64-issue roofline figures are priced at). */
 int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 
-/* Selects a kernel variant / diagnostic by name ("br_variant", "ks_variant", "br_small", "br_tiny", "br_prio_pct",
- * "measure_margin", "mk_general", "mk_variant", "mkg_acc", "ks_slices", ...: the full list is in tfhe_set_option,
+/* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
+ * "measure_margin", "mk_general", "mk_variant", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
  * csrc/tfhe_engine.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
  * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);

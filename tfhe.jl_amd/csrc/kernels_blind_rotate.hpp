@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     // KPF == 8: the first half of a transform's key chunk is requested a transform ahead, the first KMID values of the
     // second half inside the transform (between the store and the load of its second transposition, where x[] is dead),
     // the rest after it.  Interleaved A/B on one device, 4096 rotations: l = 2: 12.86 ms against 13.07 with the whole chunk
-    // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  The dispatcher picks by l.
+    // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  Only <l, 8, tw2reg> is instantiated since round 4.
 #ifdef TFHE_V3_KMID      // A/B builds only
     constexpr int KMID = (KPF == 8) ? TFHE_V3_KMID : 0;
 #else
