@@ -12,7 +12,7 @@ sk, ck = tfhe.make_key_pair(rng, tfhe.tfhe_parameters_80() if a.params == "80" e
 eng = ck.engine(0)
 eng.set_option("pipeline_min", -1)        # single launches: kernel times are of the whole batch
 print(f"| rotations | kernel | blind rotate ms | µs per rotation | host wall ms |\n|---|---|---|---|---|")
-for B in (1, 16, 64, 256, 300, 512, 700, 1024, 1100, 1536, 2048, 3072, 4096, 8192, 16384):
+for B in (1, 16, 64, 256, 300, 512, 700, 1024, 1100, 1536, 2048, 2560, 3072, 4096, 5000, 8192, 9900, 16384):
     x = tfhe.encrypt(rng, sk, rng.integers(0, 2, B).astype(bool)).data
     y = tfhe.encrypt(rng, sk, rng.integers(0, 2, B).astype(bool)).data
     ops = np.zeros(B, np.uint8)

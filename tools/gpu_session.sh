@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: tests, bench line, other configs, profiles.  Usage: bash tools/gpu_session.sh <tag> [steps...]
-# steps (default all): test bench configs prof2 prof4a prof4b prof5 (also: profmk4 profmk8 testall)
+# steps (default all): test bench configs prof2 prof4a prof4b prof5 (also: profmk4 profmk8 testall sweep circuit)
 # Every step runs under its own `timeout -k 10`; a step that times out or is killed ends the session (no further GPU step).
 TAG=${1:-run}; shift
 STEPS=${@:-test bench configs prof2 prof4a prof4b prof5}
@@ -26,6 +26,8 @@ for s in $STEPS; do
     prof5)   run 600 prof5 bash tools/profile.sh ${TAG}_cfg5 tools/run_config.py --config 5 --reps 9 > gpurun_out/${TAG}_prof5.log 2>&1; tail -12 gpurun_out/${TAG}_prof5.log ;;
     profmk4) run 600 profmk4 bash tools/profile.sh ${TAG}_mk4 tools/run_config.py --config mk4 --reps 9 > gpurun_out/${TAG}_profmk4.log 2>&1; tail -12 gpurun_out/${TAG}_profmk4.log ;;
     profmk8) run 900 profmk8 bash tools/profile.sh ${TAG}_mk8 tools/run_config.py --config mk8 --reps 6 > gpurun_out/${TAG}_profmk8.log 2>&1; tail -12 gpurun_out/${TAG}_profmk8.log ;;
+    sweep)   run 400 sweep80 bash -c "python tools/dispatch_sweep.py --params 80 > gpurun_out/${TAG}_dispatch_sweep_80bit.md 2>&1"; run 400 sweep128 bash -c "python tools/dispatch_sweep.py --params 128 > gpurun_out/${TAG}_dispatch_sweep_128bit.md 2>&1"; cat gpurun_out/${TAG}_dispatch_sweep_80bit.md gpurun_out/${TAG}_dispatch_sweep_128bit.md ;;
+    circuit) run 300 circuit bash -c "python tools/circuit_timing.py > gpurun_out/${TAG}_circuit_timing.txt 2>&1"; cat gpurun_out/${TAG}_circuit_timing.txt ;;
     *) run 600 custom bash -c "$s" ;;
   esac
 done
