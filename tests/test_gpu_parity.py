@@ -238,6 +238,52 @@ def test_ragged_batch_sizes(tfhe, orc, keys80, eng80, B):
     assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=16))
 
 
+@pytest.mark.parametrize("B", [2560, 3072, 5000])
+def test_split_dispatch_of_part_filled_rounds(tfhe, orc, keys80, eng80, B):
+    """Batches above what the chip holds whose last round is at most 1024 rotations: the whole rounds go to the one-wave
+    kernel, the tail to the two-wave kernel in a second launch (launch_blind_rotate, round 4).  Rows around the seam and at
+    both ends equal the oracle; the whole batch equals the single-launch result (option br_split 0) word for word."""
+    K = keys80
+    rng = np.random.default_rng(B)
+    bx, by = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    x, y = tfhe.encrypt(K.rng, K.sk, bx).data, tfhe.encrypt(K.rng, K.sk, by).data
+    ops = np.zeros(B, np.uint8)
+    eng80.set_option("pipeline_min", -1)           # one call = one batch (no two-stream halves)
+    try:
+        got = eng80.gates(ops, x, y)
+        name = eng80.last_kernel_name()
+        head = B - B % 2048
+        assert name.startswith("blind_rotate_kernel_v3<2,8,tw2reg,rw4> + blind_rotate_kernel_w2<2"), name
+        idx = sorted({0, 1, head - 2, head - 1, head, head + 1, B - 2, B - 1} | set(int(v) for v in rng.choice(B, 24, replace=False)))
+        assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+        assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
+        eng80.set_option("br_split", 0)
+        one = eng80.gates(ops, x, y)
+        assert eng80.last_kernel_name() == "blind_rotate_kernel_v3<2,8,tw2reg,rw4>"
+        assert np.array_equal(one, got)
+    finally:
+        eng80.set_option("br_split", 1)
+        eng80.set_option("pipeline_min", 4096)
+
+
+def test_ragged_batch_mask_size_2(tfhe, orc):
+    """k = 2 (tlwe_mask_size keyword, api.jl:30): a batch that is not a multiple of the 1792 rotations a round of the lockstep
+    groups holds — 2000 mixed gates, rows from every round and the seams against the oracle."""
+    from conftest import KeySet
+    K = KeySet(tfhe, orc, tfhe.SchemeParameters(24, 1 / 2**15, 1024, 2, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1), seed=777)
+    eng = K.ck.engine(0)
+    B = 2000
+    rng = np.random.default_rng(2)
+    names = ["NAND", "XOR", "MUX", "NOT", "ANDYN"]
+    ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
+    ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+    got = eng.gates(ops, *ins)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
+    idx = sorted({0, 1, 255, 256, 1791, 1792, 1793, B - 1} | set(int(v) for v in rng.choice(B, 40, replace=False)))
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], *[a[idx] for a in ins], nthreads=16))
+    K.ck.close()
+
+
 def test_streamed_batches_equal_synchronous(tfhe, orc, keys80, eng80):
     """tfhe_gates_batch_submit / _wait: six batches of different sizes and opcode mixes streamed two at a time from
     page-locked buffers — every result bit-equal to the blocking call's; a third submit displaces (waits for) the oldest

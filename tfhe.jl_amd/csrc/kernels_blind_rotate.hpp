@@ -509,106 +509,6 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
     dft8<true>(x);
 }
 
-template <int L, int PARTY, bool MARGIN>
-__device__ __forceinline__ void mk_party_steps(int lane, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
-                                               cplx *xch, const cplx *tw2_lds, const cplx (&tw1f)[8], int32_t xormask, double &worst)
-{
-    constexpr int NP = 2;                         // parties
-    constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit)
-    const int beta = P.g.log2_base;
-#pragma unroll 1
-    for (int j = 0; j < P.n; j++) {
-        const int a = bara[PARTY * P.n + j] & (2 * kN - 1);
-        const cplx *key = P.bk + ((size_t)PARTY * P.n + j) * PER * kM + lane;
-        cplx out[NP + 1][8];
-#pragma unroll
-        for (int d = 0; d <= NP; d++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) out[d][q] = mk(0.0, 0.0);
-#pragma unroll
-        for (int s = 0; s <= NP; s++) {           // source polynomial: masks 0..NP-1, body NP
-            int32_t temp[16];
-            rotate_poly<16>(lane, a, acc_lds + s * kImg, P.g.offset, xormask, temp);
-#pragma unroll 1
-            for (int p = 0; p < L; p++) {
-                // key polys for this transform (mk_internals.jl:371-385); the two every source needs are requested
-                // before the FFT (small batches leave one wave per SIMD: nobody else hides an L2 round trip)
-                const cplx *k_party, *k_body, *k_other = nullptr;
-                if (s < NP) {
-                    k_party = key + (size_t)(L * NP + p * NP + s) * kM;         // y[p, s]      -> a'_party
-                    k_body = key + (size_t)(p * NP + s) * kM;                   // x[p, s]      -> b'
-                    if (s != PARTY) k_other = key + (size_t)(L * NP + p * NP + PARTY) * kM;   // y[p, party] -> a'_s
-                } else {
-                    k_party = key + (size_t)(2 * L * NP + L + p) * kM;          // c1[p]        -> a'_party
-                    k_body = key + (size_t)(2 * L * NP + p) * kM;               // c0[p]        -> b'
-                }
-                cplx kpa[8], kbo[8];
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) { kpa[k2] = k_party[k2 * 64]; kbo[k2] = k_body[k2 * 64]; }
-                cplx x[8];
-                load_digits2(temp, p + 1, beta, x);
-                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
-                cplx kv[8];
-                if (s < NP && s != PARTY) {
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = k_other[k2 * 64];
-                }
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[PARTY][k2] = cfma(x[k2], kpa[k2], out[PARTY][k2]);
-#pragma unroll
-                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cfma(x[k2], kbo[k2], out[NP][k2]);
-                if (s < NP && s != PARTY) {
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[s < NP ? s : 0][k2] = cfma(x[k2], kv[k2], out[s < NP ? s : 0][k2]);
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 0; d <= NP; d++) {
-            fft_inv_wave(lane, out[d], tw1f, tw2_lds, xch);
-            accumulate_poly<MARGIN>(lane, out[d], acc_lds + d * kImg, &worst);
-        }
-        WAVE_LDS_FENCE();
-    }
-}
-
-template <int L, bool MARGIN = false>
-__global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
-{
-    constexpr int NP = 2;
-    unsigned long long dg_t0 = 0, dg_r0 = 0;
-    diag_begin<MARGIN>(dg_t0, dg_r0);
-    double worst = 0.0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem);                    // [NP+1][kImg]
-    cplx *xch = reinterpret_cast<cplx *>(smem + (NP + 1) * kImg * 4);        // [kXchElems]
-    cplx *tw2_lds = xch + kXchElems;                                         // [8][8]
-    const int lane = threadIdx.x;
-    const size_t w = blockIdx.x;
-    const int32_t *bara = P.bara + w * (NP * P.n + 1);
-    const int32_t xormask = gadget_xor_mask(L, P.g.log2_base);
-
-    cplx tw1f[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
-    tw2_lds[lane] = P.T.tw2[lane];
-    // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
-    init_zero_poly(lane, acc_lds);
-    init_zero_poly(lane, acc_lds + kImg);
-    init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
-    WAVE_LDS_FENCE();
-    // party-major double loop (mk_internals.jl:475-476)
-    mk_party_steps<L, 0, MARGIN>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask, worst);
-    mk_party_steps<L, 1, MARGIN>(lane, P, bara, acc_lds, xch, tw2_lds, tw1f, xormask, worst);
-
-    // mk_tlwe_extract_sample (mk_internals.jl:88-95): one extracted mask column per party, b = body[0]
-    int32_t *ext = P.ext + w * (NP * kN + 1);
-#pragma unroll
-    for (int c = 0; c < NP; c++) extract_mask_poly(lane, acc_lds + c * kImg, ext + c * kN);
-    if (lane == 0) ext[NP * kN] = acc_lds[NP * kImg + kMir];
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
-}
-
 // ---- multi-key blind rotation, 2 parties, TWO waves per rotation ------------------------------------------------
 // BASELINE config 5 is 1024 rotations: with one wave per rotation that is ONE wave per SIMD (a lone wave issues FP64 at
 // about half the SIMD's rate) running 12 forward and 3 inverse transforms per step back to back.  Here the two waves of
@@ -617,7 +517,7 @@ __global__ __launch_bounds__(64, 1) void mk_blind_rotate_kernel(MkBrArgs P)
 // partial sums of the three new polynomials (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
 // wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
 // polynomials.  Two barriers per step (hand-off written / accumulator updated).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
-// reuses the transposition buffers).  Same words as mk_blind_rotate_kernel.  L must be even.
+// reuses the transposition buffers).  Same words as the any-party kernel (round 3's one-wave 2-party kernel is gone).  L must be even.
 template <int L, int PARTY, int WV, bool MARGIN>
 __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                 cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
@@ -795,7 +695,7 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
 }
 
 // ---- multi-key blind rotation, any number of parties (2..8) and any decomposition length (<= 8) ------------
-// Same algorithm as mk_blind_rotate_kernel with run-time P and L.  Only three spectrum accumulators are ever
+// The multi-key blind rotation (header above MkBrArgs) with run-time P and L.  Only three spectrum accumulators are ever
 // live whatever P is: in step (party i, bit j) the new mask a'_s of a non-party s receives products of its OWN
 // digits only (mk_internals.jl:377-378), so it is inverse-transformed and written back right after source s's
 // L transforms (nobody else reads acc[s] in this step); a'_party and b' accumulate over all sources

@@ -125,7 +125,6 @@ struct tfhe_ctx {
     int mkg_acc = -1;              // any-party kernel: accumulators in LDS (0) / in global memory (1) / by party count (-1: global above 4 parties)
     int mk_rw = 0;                 // two-wave 2-party kernel: rotations per workgroup advancing in lockstep (tfhe_set_option("mk_rw", 0|1|2); 0 = one
                                    //  up to one rotation per CU (single mk_gate_nand 11.7 vs 13.7 ms), two beyond)
-    int mk_variant = 2;            // 2-party kernel: 2 = two waves per rotation (default; l = 4, the shipped 2-party set), 1 = one wave
     bool measure_margin = false;   // tfhe_set_option("measure_margin", 1): blind rotations run their DIAG instantiation
     // Host-buffer batches of at least `pipeline_min` gates are cut in two rotation-balanced halves that run on two streams of
     // this device, so that the second half's upload and the first half's download cross PCIe while the other half computes.
@@ -744,7 +743,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         Br2048Args b;
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
-        const int rw = c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);
+        const int rw = dg ? 1 : c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);     // (the DIAG instantiation exists for single rotations only)
         const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
 #define LAUNCH_2048(DG, RWV)                                                                                       \
@@ -753,9 +752,8 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
                 HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_n2048x<3, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
             hipLaunchKernelGGL((blind_rotate_kernel_n2048x<3, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b); \
         } while (0)
-        if (rw == 2 && dg) LAUNCH_2048(true, 2);
+        if (dg) LAUNCH_2048(true, 1);
         else if (rw == 2) LAUNCH_2048(false, 2);
-        else if (dg) LAUNCH_2048(true, 1);
         else LAUNCH_2048(false, 1);
 #undef LAUNCH_2048
         HIP_TRY(c, hipGetLastError());
@@ -871,8 +869,9 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 // interleaved (profiles/r04/r04c_split80.jsonl, 80-bit set; the parts alone: 2048 rotations 5.87 ms, 1024: 3.33, 512: 2.27):
 //     2560 rotations 8.79 vs 9.84 ms in one launch, 3072: 9.53 vs 9.70, 5000: 15.29 vs 15.56, 6400: 19.58 vs 21.18;
 //     128-bit set 3072: 15.43 vs 15.92, 5000: 24.57 vs 25.26.
-// Likewise a batch just above br_small: the first br_small rotations on the two-wave kernel, up to one rotation per CU more
-// on the 4 l-wave kernel (1100 rotations: 3.3 + 1.8 ms instead of 5.4 on the one-wave kernel).
+// (Measured and removed: the same for a batch just above br_small — the first 1024 rotations on the two-wave kernel, up to one
+//  rotation per CU more on the 4 l-wave kernel.  1100 rotations: 5.20 ms against 5.01 on the one-wave kernel (80-bit set), 8.41
+//  against 8.41 (128-bit set): the second launch costs what the better packing saves.)
 // (Measured dead end: the tail on a second stream, launched first so that the whole rounds move into the slots it frees —
 //  3072 rotations 9.39 ms, but 2560: 10.7 and 5000: 15.8: whichever kernel the dispatcher favours starves the other.)
 // Option br_split (default 1; 0: always one launch).
@@ -884,10 +883,8 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     const size_t resident = 8 * (size_t)c->cu_count;          // rotations of blind_rotate_kernel_v3 on the chip
     const bool family = c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general && c->br_split && c->br_small > 0;
     const size_t small = family ? (size_t)c->br_small : 0;
-    const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
     size_t head = 0;                                          // rotations of the first launch; 0: one launch
     if (family && R > resident && R % resident > 0 && R % resident <= small) head = R - R % resident;
-    else if (family && R > small && small <= resident / 2 && tiny > 0 && R - small <= (size_t)tiny) head = small;
     if (head) {
         rc = launch_blind_rotate_part(c, 0, head, mu, s, diag);
         if (rc) return rc;
@@ -1876,12 +1873,13 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     a.n = n; a.mu = (int32_t)(1u << 29); a.R = (int32_t)B;
     a.prio_steps = (int32_t)((int64_t)NP * n * c->br_prio_pct / 100);
     const size_t lds = (size_t)(NP + 1) * kImg * 4 + (kXchElems + 64) * sizeof(cplx);
-    // 2 parties with l = 4 (mktfhe_parameters_2party, mk_api.jl:4-10): the tuned kernels; any other shape: the any-party kernel
+    // 2 parties with l = 4 (mktfhe_parameters_2party, mk_api.jl:4-10): the tuned two-wave kernel; any other shape, and option
+    // mk_general, the any-party kernel (round 3's one-wave 2-party kernel is gone: the any-party kernel is the cross-check)
     const bool special = (NP == 2 && c->P.bs_l == 4 && !c->mk_force_general);
-    if (special && c->mk_variant == 2) {
+    if (special) {
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
-        // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four)
-        const int rw = c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
+        // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four; DIAG: 1)
+        const int rw = dg ? 1 : c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
         const size_t lds2 = (size_t)rw * ((NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         a.R = (int32_t)B;
@@ -1891,16 +1889,11 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
                 HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w2<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
             hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), lds2, s, a);  \
         } while (0)
-        if (rw == 2 && dg) LAUNCH_MK2(4, true, 2);
+        if (dg) LAUNCH_MK2(4, true, 1);
         else if (rw == 2) LAUNCH_MK2(4, false, 2);
-        else if (dg) LAUNCH_MK2(4, true, 1);
         else LAUNCH_MK2(4, false, 1);
 #undef LAUNCH_MK2
         name_kernel(c, "mk_blind_rotate_kernel_w2<%d>", c->P.bs_l);
-    } else if (special) {
-        if (dg) hipLaunchKernelGGL((mk_blind_rotate_kernel<4, true>), dim3((unsigned)B), dim3(64), lds, s, a);
-        else hipLaunchKernelGGL((mk_blind_rotate_kernel<4, false>), dim3((unsigned)B), dim3(64), lds, s, a);
-        name_kernel(c, "mk_blind_rotate_kernel<%d>", c->P.bs_l);
 #ifndef TFHE_NO_G2      // (-DTFHE_NO_G2: quick development builds without the many-party two-wave kernel, 1 instead of 5 minutes)
     } else if (!c->mk_force_general && c->mkg_variant != 1 && ((NP == 4 && c->P.bs_l == 5) || (NP == 8 && c->P.bs_l == 8))) {
         // the shipped 4- and 8-party sets (mk_api.jl:16-34): compile-time (parties, l), two waves per rotation at two waves per
@@ -1920,10 +1913,10 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         //  8 parties 298 vs 374 ms at 256 — profiles/r03/r03j_*)
         // 4 parties: the five accumulator images (21.8 KB per rotation) fit LDS beside the transposition buffers at four
         // rotations per CU — 81 408 B per pair of rotations = 40 LDS granules of 2 KB, two pairs or one group of four per CU —
-        // so the step needs neither the trip to L2 nor the workgroup-scope fence (round 4; option mkg_acc 1: global memory as at
-        // 8 parties, where nine images do not fit — kept for A/B with four rotations per workgroup only)
-        const bool acc_lds = NP == 4 && (c->mkg_acc != 1 || dg);
-        const int rw = dg ? 2 : (NP == 4 && !acc_lds) ? 4 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : ((size_t)B <= 2 * (size_t)c->cu_count ? 2 : 4);
+        // so the step needs neither the trip to L2 nor the workgroup-scope fence (round 4: 66.2 vs 73.6 ms; at 8 parties nine
+        // images do not fit and the accumulators stay in global memory)
+        const bool acc_lds = NP == 4;
+        const int rw = dg ? 2 : (c->mkg_rw == 2 || c->mkg_rw == 4) ? c->mkg_rw : ((size_t)B <= 2 * (size_t)c->cu_count ? 2 : 4);
         const size_t ldsg2 = (size_t)rw * 2 * kXchElems * sizeof(cplx) + 64 * sizeof(cplx) + (acc_lds ? (size_t)rw * (NP + 1) * kImg * sizeof(int32_t) : 0);
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         ga.acc = nullptr;
@@ -1945,7 +1938,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         // (two rotations per workgroup: 82 vs 86 ms with four or one at 4 parties, 476 vs 481 / 765 at 8 — round 2; the three- and
         //  four-rotation instantiations are gone)
         int rw = (int)std::min<size_t>(2, (160 * 1024) / lds_rot);
-        if (c->mkg_rw == 1 || B < 2 || rw < 1) rw = 1;
+        if (c->mkg_rw == 1 || B < 2 || rw < 1 || dg) rw = 1;       // (the DIAG instantiations exist for single rotations only)
         const size_t ldsg = (size_t)rw * lds_rot;
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         ga.acc = nullptr;
@@ -1961,10 +1954,9 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
             if (accg) hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, true>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
             else hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, false>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
         } while (0)
-#define LAUNCH_MKG_RW(RWV) do { if (dg) LAUNCH_MKG(true, RWV); else LAUNCH_MKG(false, RWV); } while (0)
-        if (rw == 2) LAUNCH_MKG_RW(2);
-        else LAUNCH_MKG_RW(1);
-#undef LAUNCH_MKG_RW
+        if (dg) LAUNCH_MKG(true, 1);
+        else if (rw == 2) LAUNCH_MKG(false, 2);
+        else LAUNCH_MKG(false, 1);
 #undef LAUNCH_MKG
         name_kernel(c, accg ? "mk_blind_rotate_kernel_general(P=%d,L=%d,acc=global)" : "mk_blind_rotate_kernel_general(P=%d,L=%d)", NP, c->P.bs_l);
     }
@@ -2257,11 +2249,6 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "mk_rw")) {
         if (value != 0 && value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_rw must be 0 (by batch size), 1 or 2");
         c->mk_rw = (int)value;
-        return TFHE_OK;
-    }
-    if (!strcmp(name, "mk_variant")) {
-        if (value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: mk_variant must be 1 (one wave per rotation) or 2 (two waves)");
-        c->mk_variant = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "ks_variant")) {
