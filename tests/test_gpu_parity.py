@@ -225,10 +225,11 @@ def test_gate_parity_synthetic_n2048(tfhe, orc):
     K.ck.close()
 
 
-@pytest.mark.parametrize("B", [2, 31, 33, 65, 255, 257, 513, 1027, 1300])
+@pytest.mark.parametrize("B", [2, 31, 33, 65, 255, 257, 513, 1027, 1300, 2600])
 def test_ragged_batch_sizes(tfhe, orc, keys80, eng80, B):
     """Batch sizes straddling every tile edge (MFMA keyswitch tiles of 32/64/256 samples, the 1024-rotation switch
-    between the two-wave and one-wave blind-rotate kernels — MUX counts twice, NOT not at all): all bit-equal to the oracle."""
+    between the two-wave and one-wave blind-rotate kernels, a mixed batch whose rotation count leaves a part-filled last
+    round (2600 gates: the split launch) — MUX counts twice, NOT not at all): all bit-equal to the oracle."""
     K = keys80
     rng = np.random.default_rng(B)
     names = ["NAND", "XOR", "MUX", "NOT", "ANDYN"]
