@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run (lives under tests/ because it uses the oracle as the checker; not collected by pytest — run it as
 `python tests/soak_run.py [iterations]` on a GPU box): random batch sizes and opcode mixes against the oracle (every output word for small batches, a random
-sample for large ones) plus decrypt checks, alternating the host-buffer API and the wire-table level API."""
+sample for large ones) plus decrypt checks, alternating the host-buffer API, the wire-table level API and — on a
+{0, 0} multi-device context — streamed submits and sharded levels."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
@@ -11,6 +12,8 @@ from conftest import KeySet
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 K = KeySet(tfhe, oracle, tfhe.tfhe_parameters_80())
 eng = K.ck.engine(0)
+multi = K.ck.engine([0, 0])
+multi.set_option("level_split_min", 64)
 rng = np.random.default_rng(2026)
 names = list(tfhe.OPCODES)
 truth = {"NAND": lambda x, y, z: ~(x & y), "OR": lambda x, y, z: x | y, "AND": lambda x, y, z: x & y, "XOR": lambda x, y, z: x ^ y,
@@ -25,14 +28,19 @@ for it in range(iters):
     ops = np.array([tfhe.OPCODES[names[s]] for s in sel], np.uint8)
     bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
     ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
-    if it % 2 == 0:
+    mode = ("batch", "level", "multi-submit", "multi-level")[it % 4]
+    if mode == "batch":
         got = eng.gates(ops, *ins)
-    else:                                    # same gates through the wire table, one level
-        eng.wires_alloc(4 * B)
-        eng.wires_upload(0, np.concatenate(ins))
+    elif mode == "multi-submit":             # two device contexts, every one takes its shard as a submit of its own
+        t, got = multi.gates_submit(ops, *ins)
+        multi.gates_wait(t)
+    else:                                    # same gates through the wire table, one level (sharded on the multi-device context)
+        e = eng if mode == "level" else multi
+        e.wires_alloc(4 * B)
+        e.wires_upload(0, np.concatenate(ins))
         idx = np.arange(B, dtype=np.int32)
-        eng.gates_level(ops, idx, idx + B, idx + 2 * B, idx + 3 * B)
-        got = eng.wires_download(3 * B, B)
+        e.gates_level(ops, idx, idx + B, idx + 2 * B, idx + 3 * B)
+        got = e.wires_download(3 * B, B)
     want_bits = np.zeros(B, bool)
     for k, nm in enumerate(names):
         m = sel == k
@@ -42,5 +50,5 @@ for it in range(iters):
     samp = np.arange(B) if B <= 128 else rng.choice(B, 128, replace=False)
     want = K.oracle.gates(ops[samp], *[a[samp] for a in ins], nthreads=32)
     assert np.array_equal(got[samp], want), f"iter {it}: word mismatch"
-    print(f"iter {it:3d} B={B:5d} ok ({'level' if it % 2 else 'batch'})", flush=True)
+    print(f"iter {it:3d} B={B:5d} ok ({mode})", flush=True)
 print(f"soak ok: {iters} iterations in {time.time() - t0:.1f} s")
