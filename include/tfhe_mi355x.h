@@ -189,9 +189,10 @@ int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *i
  * batch first waits for the oldest.  in0/in1/in2/out must stay valid and untouched until the batch has been waited
  * for, and should come from tfhe_host_alloc: the runtime stages copies from pageable memory synchronously, which
  * overlaps nothing.  `opcodes` is read before submit returns.  *ticket identifies the batch for tfhe_gates_batch_wait
- * (waiting twice, or for a batch a later submit already displaced, is harmless).  Contexts that cannot run two batches
- * side by side (several devices, multi-key, measure_margin) complete the batch inside submit.  The timing queries
- * below see only the batches that ran on the context's own stream (every other one). */
+ * (waiting twice, or for a batch a later submit already displaced, is harmless).  On a multi-device context every device
+ * takes its shard as a submit of its own.  Contexts that cannot run two batches side by side (multi-key, measure_margin)
+ * complete the batch inside submit.  The timing queries below see only the batches that ran on the context's own stream
+ * (every other one). */
 int32_t tfhe_gates_batch_submit(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                                 const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket);
 int32_t tfhe_gates_batch_wait(tfhe_ctx *ctx, int32_t ticket);
@@ -291,7 +292,7 @@ int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
 int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 
 /* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
- * "measure_margin", "mk_general", "mk_variant", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
+ * "measure_margin", "mk_general", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
  * csrc/tfhe_engine.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
  * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
