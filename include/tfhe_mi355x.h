@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 4
+#define TFHE_MI355X_ABI_VERSION 5
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -272,6 +272,10 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
  * took the context's own stream (every other one); a blocking host-buffer call that ran as two halves contributes the half
  * on the own stream (tfhe_last_timing_ms spans both). */
 int32_t tfhe_timing_history_ms(tfhe_ctx *ctx, int32_t which, float *ms, int32_t max_calls, int32_t *n_out);
+
+/* Number of device contexts that took part in the most recent batch / level call (1 on a one-device context; on a
+ * multi-device context: how many devices the call was sharded over — a narrow circuit level runs on the first one).  ABI v5. */
+int32_t tfhe_last_device_count(const tfhe_ctx *ctx);
 
 /* Number of blind rotations the most recent batch call executed (MUX counts 2). */
 int64_t tfhe_last_rotation_count(const tfhe_ctx *ctx);

@@ -99,6 +99,16 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
             multi.set_option("level_split_min", split)
             got = circ.run(K.ck, enc, device=[0, 0]).data
             assert np.array_equal(got, want), split
+            # the last level of both circuits is 16 parallel MUXes = 32 rotations: sharded over both device contexts iff the
+            # threshold allows it (tfhe_last_device_count, ABI v5)
+            assert multi.last_device_count() == (1 if split == 4096 else 2), split
+    # a level of ONE gate is never sharded, whatever the threshold
+    multi.set_option("level_split_min", 1)
+    multi.wires_alloc(4)
+    multi.wires_upload(0, enc.data[:2])
+    multi.gates_level(np.array([0], np.uint8), np.array([0], np.int32), np.array([1], np.int32), None, np.array([2], np.int32))
+    assert multi.last_device_count() == 1
+    assert np.array_equal(multi.wires_download(2, 1), K.ck.engine(0).gates(np.array([0], np.uint8), enc.data[:1], enc.data[1:2]))
     # intermediate wires are coherent too: every wire of the table, read back from the first device
     circ = tutorial_min_circuit(tfhe, 16)
     multi.set_option("level_split_min", 8)

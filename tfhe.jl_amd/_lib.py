@@ -21,9 +21,9 @@ ABI_SYMBOLS = [
     "tfhe_ctx_create_multi", "tfhe_ctx_device_count", "tfhe_shard_bounds", "tfhe_wires_gather",
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
     "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key", "tfhe_host_alloc", "tfhe_host_free",
-    "tfhe_timing_history_ms", "tfhe_gates_batch_submit", "tfhe_gates_batch_wait",
+    "tfhe_timing_history_ms", "tfhe_gates_batch_submit", "tfhe_gates_batch_wait", "tfhe_last_device_count",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -105,6 +105,8 @@ def load():
         lib.tfhe_timing_history_ms.argtypes = [vp, i32, C.POINTER(C.c_float), i32, C.POINTER(i32)]
     lib.tfhe_last_rotation_count.argtypes = [vp]
     lib.tfhe_last_rotation_count.restype = i64
+    lib.tfhe_last_device_count.argtypes = [vp]
+    lib.tfhe_last_device_count.restype = i32
     lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
     lib.tfhe_last_rounding_margin.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tfhe_wires_alloc.argtypes = [vp, i64]
@@ -396,6 +398,10 @@ class Engine:
 
     def last_rotation_count(self):
         return int(self._lib.tfhe_last_rotation_count(self._h))
+
+    def last_device_count(self):
+        """Device contexts the last batch / level call was sharded over (1 on a one-device context)."""
+        return int(self._lib.tfhe_last_device_count(self._h))
 
     def last_rounding_margin(self):
         m = C.c_double(0)

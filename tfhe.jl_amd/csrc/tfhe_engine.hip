@@ -253,8 +253,8 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d or %d (got %d)", kN, kN2, p.N);
         return fail(TFHE_ERR_UNSUPPORTED, buf);
     }
-    // Single key: every (k <= 4, l with l * beta <= 32, N in {1024, 2048}) runs — on a specialised kernel where one was
-    // instantiated (k <= 2 and l <= 4 at N = 1024, k = 1 and l <= 4 at N = 2048), on blind_rotate_kernel_general otherwise:
+    // Single key: every (k <= 4, l with l * beta <= 32, N in {1024, 2048}) runs — on a tuned kernel where one was
+    // instantiated (k <= 2 with l = 2 or 3 at N = 1024; k = 1, l = 3 at N = 2048), on blind_rotate_kernel_general otherwise:
     // SchemeParameters is unvalidated and tlwe_mask_size a free keyword in the reference (api.jl:4-21,30,55).
     if (p.N == kN2 && p.parties != 1)
         return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key is supported with N = 1024 only (the reference ships no other multi-key set, mk_api.jl:4-34)");
@@ -2063,6 +2063,15 @@ int32_t tfhe_timing_history_ms(tfhe_ctx *c, int32_t which, float *ms, int32_t ma
     return TFHE_OK;
 }
 
+int32_t tfhe_last_device_count(const tfhe_ctx *c)
+{
+    if (!c) return -1;
+    if (!c->multi()) return 1;
+    int32_t n = 0;
+    for (size_t k = 0; k < c->kids.size(); k++) n += c->kid_ran[k] ? 1 : 0;
+    return n;
+}
+
 int64_t tfhe_last_rotation_count(const tfhe_ctx *c)
 {
     if (!c) return -1;
@@ -2187,6 +2196,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!name || !*name) return TFHE_OK;
     if (c->multi()) {
+        if (!strcmp(name, "level_split_min")) { c->level_split_min = value; return TFHE_OK; }       // the one option that belongs to the fan-out context itself
         for (tfhe_ctx *k : c->kids) {
             const int32_t rc = tfhe_set_option(k, name, value);
             if (rc) { c->err = k->err; return rc; }
@@ -2197,7 +2207,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
-    if (!strcmp(name, "level_split_min")) { c->level_split_min = value; return TFHE_OK; }
+    if (!strcmp(name, "level_split_min")) return TFHE_OK;      // (meaningful on a multi-device context only)
     if (!strcmp(name, "br_prio_pct")) {
         if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
         c->br_prio_pct = (int)value;
