@@ -244,3 +244,40 @@ def test_noiseless_random_mask_kat_gpu(tfhe, n, N, l, beta):
         eng.set_option("br_tiny", -1); eng.set_option("br_small", -1)           # the one-wave kernel as well
         _kat_check(eng.bootstrap(2**29, x, with_keyswitch=False), phase, s, K, N, l, beta, 2**29)
     eng.close()
+
+
+# ---- (a') the schoolbook restatement at the SHIPPED sizes --------------------------------------------------------------------
+def _full_size_case(tfhe, keys, rows):
+    K = keys
+    p = K.params
+    sb = Schoolbook(p.lwe_size, p.tlwe_polynomial_degree, p.tlwe_mask_size, p.bs_decomp_length, p.bs_log2_base,
+                    p.ks_decomp_length, p.ks_log2_base, K.ck.bootstrap_key, K.ck.keyswitch_key)
+    rng = np.random.default_rng(8080)
+    bits = rng.integers(0, 2, (2, rows)).astype(bool)
+    x, y = tfhe.encrypt(K.rng, K.sk, bits[0]).data, tfhe.encrypt(K.rng, K.sk, bits[1]).data
+    # the NAND prologue written here (gates.jl:15-18: (0, 1/8) - x - y), then the schoolbook bootstrap with mu = 1/8
+    pre = wrap32(-x.astype(np.int64) - y.astype(np.int64))
+    pre[:, -1] = wrap32(pre[:, -1] + 2**29)
+    want = np.stack([sb.bootstrap(2**29, row) for row in pre]).astype(np.int32)
+    return x, y, bits, want
+
+
+def test_oracle_equals_schoolbook_full_size_80bit(orc, tfhe, keys80):
+    """tfhe_parameters_80 at its shipped size (n = 500, 500 CMUX steps): one NAND gate of the oracle against the integer
+    schoolbook restatement, word for word (4 s of numpy convolutions)."""
+    x, y, bits, want = _full_size_case(tfhe, keys80, 1)
+    got = keys80.oracle.gates(np.zeros(1, np.uint8), x, y)
+    assert np.array_equal(got, want)
+    assert list(tfhe.decrypt(keys80.sk, got)) == [not (bits[0][0] and bits[1][0])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["80", "128"])
+def test_gpu_equals_schoolbook_full_size(tfhe, keys80, keys128, which):
+    """The shipped parameter sets at full size: NAND gates through tfhe_gates_batch against the schoolbook restatement —
+    no oracle call.  Two gates each (500 / 630 CMUX steps of eight / twelve 1024-coefficient integer products)."""
+    K = keys80 if which == "80" else keys128
+    x, y, bits, want = _full_size_case(tfhe, K, 2)
+    got = K.ck.engine(0).gates(np.zeros(2, np.uint8), x, y)
+    assert np.array_equal(got, want)
+    assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bits[0] & bits[1]))
