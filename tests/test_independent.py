@@ -281,3 +281,103 @@ def test_gpu_equals_schoolbook_full_size(tfhe, keys80, keys128, which):
     got = K.ck.engine(0).gates(np.zeros(2, np.uint8), x, y)
     assert np.array_equal(got, want)
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bits[0] & bits[1]))
+
+
+# ---- (a'') multi-key (config 5): mk_gate_nand in exact integer arithmetic ------------------------------------------------------
+class MKSchoolbook(Schoolbook):
+    """mk_gate_nand (mk_gates.jl:7-12) -> mk_bootstrap (mk_internals.jl:464-515) -> mk_tgsw_extern_mul (:348-391) ->
+    mk_keyswitch (:397-411), restated with integer schoolbook products.  Key: Int32 [P][n][2 l P + 2 l][N], per (party i,
+    bit j) the polynomials x[l][P] | y[l][P] | c0[l] | c1[l] (include/tfhe_mi355x.h); samples: a[:, 1]; ...; a[:, P]; b."""
+
+    def __init__(self, n, N, l, beta, t, gamma, parties, bk, ks):
+        self.n, self.N, self.k, self.l, self.beta, self.t, self.gamma, self.P = n, N, 1, l, beta, t, gamma, parties
+        self.mbk = np.asarray(bk, np.int64).reshape(parties, n, 2 * l * parties + 2 * l, N)
+        self.mks = np.asarray(ks, np.int64).reshape(parties, N, t, (1 << gamma) - 1, n + 1)
+
+    def mk_extern_mul(self, temp, key, party):                                   # mk_internals.jl:348-391
+        P, l, N = self.P, self.l, self.N
+        x = lambda p, q: key[p * P + q]
+        y = lambda p, q: key[l * P + p * P + q]
+        c0 = lambda p: key[2 * l * P + p]
+        c1 = lambda p: key[2 * l * P + l + p]
+        da = [self.decompose(temp[i]) for i in range(P)]                         # da[i][p]
+        db = self.decompose(temp[P])
+        out = []
+        for i in range(P):
+            if i == party:                                                       # c'_party = sum g^-1(a_j) y_j + g^-1(b) c1
+                acc = sum(negacyclic(da[j][p], y(p, j), N) for p in range(l) for j in range(P))
+                acc = acc + sum(negacyclic(db[p], c1(p), N) for p in range(l))
+            else:                                                                # c'_i = g^-1(a_i) y_party
+                acc = sum(negacyclic(da[i][p], y(p, party), N) for p in range(l))
+            out.append(wrap32(acc))
+        body = sum(negacyclic(da[i][p], x(p, i), N) for p in range(l) for i in range(P))
+        body = body + sum(negacyclic(db[p], c0(p), N) for p in range(l))
+        out.append(wrap32(body))
+        return out
+
+    def mk_gate_nand(self, xs, ys):
+        n, N, P = self.n, self.N, self.P
+        temp = wrap32(-xs.astype(np.int64) - ys.astype(np.int64))               # mk_gates.jl:8-11
+        temp[P * n] = int(wrap32(temp[P * n] + 2**29))
+        bara = [[self.decode(temp[i * n + j], 2 * N) for j in range(n)] for i in range(P)]
+        barb = self.decode(temp[P * n], 2 * N)
+        acc = [np.zeros(N, np.int64) for _ in range(P)] + [monomial(np.full(N, 2**29, np.int64), -barb, N)]
+        for i in range(P):                                                       # party-major: mk_internals.jl:475-476
+            for j in range(n):
+                if bara[i][j] == 0:
+                    continue
+                rot = [wrap32(monomial(a, bara[i][j], N) - a) for a in acc]      # mk_mux_rotate :464-470
+                prod = self.mk_extern_mul(rot, self.mbk[i, j], i)
+                acc = [wrap32(a + q) for a, q in zip(acc, prod)]
+        res = np.zeros(P * n + 1, np.int64)
+        res[P * n] = acc[P][0]                                                   # mk_tlwe_extract_sample :88-95, then mk_keyswitch
+        for p in range(P):
+            u = np.empty(N + 1, np.int64)
+            u[0] = acc[p][0]
+            u[1:N] = -acc[p][:0:-1]
+            u[N] = 0                                                             # b = 0 per party (:399-401)
+            self.ks, self.k = self.mks[p], 1
+            part = self.keyswitch(wrap32(u))
+            res[p * n:(p + 1) * n] = part[:n]
+            res[P * n] += part[n]
+        return wrap32(res)
+
+
+def _mk_setup(tfhe, parties, l, beta, n, seed):
+    p = tfhe.SchemeParameters(n, 0.012467, 1024, 1, l, beta, 3.29e-10, 8, 2, 2.44e-5, parties)
+    rng = np.random.default_rng(seed)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    sb = MKSchoolbook(n, 1024, l, beta, 8, 2, parties, ck.bootstrap_key, ck.keyswitch_key)
+    xs = tfhe.mk_encrypt(rng, sks, [True, False, True])
+    ys = tfhe.mk_encrypt(rng, sks, [True, True, False])
+    extra = rng.integers(-2**31, 2**31, size=(1, parties * n + 1), dtype=np.int64).astype(np.int32)     # an arbitrary word row
+    xs, ys = np.concatenate([xs, extra]), np.concatenate([ys, extra[:, ::-1]])
+    want = np.stack([sb.mk_gate_nand(a, b) for a, b in zip(xs, ys)]).astype(np.int32)
+    return p, sks, ck, xs, ys, want
+
+
+MK_CASES = [(2, 4, 7, 6), (4, 5, 6, 3)]      # (parties, l, beta, n): mktfhe_parameters_2party / _4party gadget shapes (mk_api.jl:4-22)
+
+
+@pytest.mark.parametrize("parties,l,beta,n", MK_CASES)
+def test_oracle_mk_equals_schoolbook(orc, tfhe, parties, l, beta, n):
+    p, sks, ck, xs, ys, want = _mk_setup(tfhe, parties, l, beta, n, 400 + parties)
+    o = orc.Oracle(n, 1024, 1, l, beta, 8, 2, parties=parties)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    assert np.array_equal(o.mk_gate_nand(xs, ys, nthreads=4), want)
+    assert list(tfhe.mk_decrypt(sks, want[:3])) == [False, True, True]
+    ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parties,l,beta,n", MK_CASES)
+def test_gpu_mk_equals_schoolbook(tfhe, parties, l, beta, n):
+    """tfhe_mk_gate_nand_batch (mk_blind_rotate_kernel_w2<4> / g2<4,5,acc=lds>) against the multi-key schoolbook — no oracle."""
+    p, sks, ck, xs, ys, want = _mk_setup(tfhe, parties, l, beta, n, 400 + parties)
+    eng = ck.engine(0)
+    assert np.array_equal(eng.mk_gate_nand(xs, ys), want)
+    assert eng.last_kernel_name() == ("mk_blind_rotate_kernel_w2<4>" if parties == 2 else "mk_blind_rotate_kernel_g2<4,5,acc=lds>")
+    ck.close()
