@@ -285,6 +285,24 @@ def test_ragged_batch_mask_size_2(tfhe, orc):
     K.ck.close()
 
 
+def test_mask_size_2_round_partition(tfhe, orc):
+    """k = 2, 4096 rotations = 16 per CU: dealt as rounds of 6 + 6 + 4 in two launches (k2_partition, round 4) instead of
+    6 + 5 + 5 in one — same words as the single launch, rows from every segment and the seam equal the oracle."""
+    from conftest import KeySet
+    K = KeySet(tfhe, orc, tfhe.SchemeParameters(16, 1 / 2**15, 1024, 2, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1), seed=778)
+    eng = K.ck.engine(0)
+    R = 4096
+    rng = np.random.default_rng(3)
+    x = rng.integers(-2**31, 2**31, size=(R, 17), dtype=np.int64).astype(np.int32)
+    got = eng.bootstrap(2**29, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
+    idx = sorted({0, 1, 3071, 3072, 3073, R - 1} | set(int(v) for v in rng.choice(R, 26, replace=False)))
+    assert np.array_equal(got[idx], K.oracle.bootstrap(2**29, x[idx], with_keyswitch=False, nthreads=16))
+    eng.set_option("br_split", 0)
+    assert np.array_equal(eng.bootstrap(2**29, x, with_keyswitch=False), got)
+    K.ck.close()
+
+
 def test_streamed_batches_equal_synchronous(tfhe, orc, keys80, eng80):
     """tfhe_gates_batch_submit / _wait: six batches of different sizes and opcode mixes streamed two at a time from
     page-locked buffers — every result bit-equal to the blocking call's; a third submit displaces (waits for) the oldest

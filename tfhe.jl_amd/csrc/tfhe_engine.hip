@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -875,26 +876,68 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 // (Measured dead end: the tail on a second stream, launched first so that the whole rounds move into the slots it frees —
 //  3072 rotations 9.39 ms, but 2560: 10.7 and 5000: 15.8: whichever kernel the dispatcher favours starves the other.)
 // Option br_split (default 1; 0: always one launch).
+//
+// k = 2 (blind_rotate_kernel_k2, lockstep groups of up to seven rotations, one workgroup per CU): a round of n rotations per
+// CU takes (one device, 80-bit set with tlwe_mask_size 2, profiles/r04/r04w_k2_rounds.jsonl)
+//     n = 1 .. 7:   6.8 / 6.8 / 7.2 / 7.3 / 9.4 / 9.5 / 10.3 ms
+// — up to one wave per SIMD costs the same 7 ms, the second wave on a SIMD 2.1 - 3 ms more — so what pays is rounds of 6 - 7
+// and a remainder of at most 4, not the equally full rounds of round 3 (4096 rotations = 16 per CU: 6 + 6 + 4 -> 26.4 ms by
+// this table against 6 + 5 + 5 -> 28.4).  k2_partition() picks the round sizes by dynamic programming over that table; rounds
+// of (nearly) equal size share a launch (the kernel deals a launch's rotations out in equally full rounds itself).
+static const double kK2RoundCost[8] = {0.0, 6.8, 6.85, 7.2, 7.3, 9.45, 9.55, 10.3};
+static std::vector<size_t> k2_partition(size_t R, size_t cus)
+{
+    const size_t q = (R + cus - 1) / cus;                    // rotations per CU, rounded up
+    if (q <= 7) return {R};
+    std::vector<double> best(q + 1, 1e300);
+    std::vector<int> take(q + 1, 0);
+    best[0] = 0.0;
+    for (size_t i = 1; i <= q; i++)
+        for (int n = 1; n <= 7 && (size_t)n <= i; n++)
+            if (best[i - n] + kK2RoundCost[n] < best[i]) { best[i] = best[i - n] + kK2RoundCost[n]; take[i] = n; }
+    std::vector<int> rounds;
+    for (size_t i = q; i > 0; i -= (size_t)take[i]) rounds.push_back(take[i]);
+    std::sort(rounds.begin(), rounds.end(), std::greater<int>());
+    // consecutive rounds of the same size -> one launch; the last launch takes what is left of R
+    std::vector<size_t> seg;
+    size_t done = 0;
+    for (size_t i = 0; i < rounds.size();) {
+        size_t j = i;
+        while (j < rounds.size() && rounds[j] == rounds[i]) j++;
+        size_t want = (size_t)rounds[i] * (j - i) * cus;
+        if (j == rounds.size() || done + want >= R) { seg.push_back(R - done); done = R; break; }
+        seg.push_back(want);
+        done += want;
+        i = j;
+    }
+    return seg;
+}
+
 static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_t s)
 {
     DiagArgs diag;
     int32_t rc = prepare_diag(c, R, s, diag);
     if (rc) return rc;
-    const size_t resident = 8 * (size_t)c->cu_count;          // rotations of blind_rotate_kernel_v3 on the chip
-    const bool family = c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general && c->br_split && c->br_small > 0;
-    const size_t small = family ? (size_t)c->br_small : 0;
-    size_t head = 0;                                          // rotations of the first launch; 0: one launch
-    if (family && R > resident && R % resident > 0 && R % resident <= small) head = R - R % resident;
-    if (head) {
-        rc = launch_blind_rotate_part(c, 0, head, mu, s, diag);
-        if (rc) return rc;
-        const std::string head_name = c->last_kernel;
-        rc = launch_blind_rotate_part(c, head, R - head, mu, s, diag);
-        if (rc) return rc;
-        c->last_kernel = head_name + " + " + c->last_kernel;
-        return TFHE_OK;
+    std::vector<size_t> seg;                                   // rotations per launch, in order
+    const bool tuned_l = c->P.bs_l == 2 || c->P.bs_l == 3;
+    if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7)) {
+        seg = k2_partition(R, (size_t)c->cu_count);
+    } else if (c->br_split && !c->br_general && c->P.N == kN && c->P.k == 1 && tuned_l && c->br_small > 0) {
+        const size_t resident = 8 * (size_t)c->cu_count;      // rotations of blind_rotate_kernel_v3 on the chip
+        if (R > resident && R % resident > 0 && R % resident <= (size_t)c->br_small) seg = {R - R % resident, R % resident};
     }
-    return launch_blind_rotate_part(c, 0, R, mu, s, diag);
+    if (seg.size() <= 1) return launch_blind_rotate_part(c, 0, R, mu, s, diag);
+    std::string names;
+    size_t first = 0;
+    for (size_t n : seg) {
+        rc = launch_blind_rotate_part(c, first, n, mu, s, diag);
+        if (rc) return rc;
+        if (names.empty() || names.substr(names.rfind(" + ") == std::string::npos ? 0 : names.rfind(" + ") + 3) != c->last_kernel)
+            names += (names.empty() ? "" : " + ") + c->last_kernel;
+        first += n;
+    }
+    c->last_kernel = names;
+    return TFHE_OK;
 }
 
 static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const int32_t *e1, const int32_t *dst,
