@@ -1452,6 +1452,20 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
         // two halves, two streams: [upload B | compute A] then [compute B | download A] overlap
         int64_t bounds[3];
         shard_bounds_by_rotations(opcodes, B, 2, bounds);
+        // ... cut at a ROUND boundary of the one-wave kernel where there is one near the middle: two halves of 4950 rotations
+        // are 2.4 rounds each (three launches' worth of partly filled rounds), 4096 + 5804 are 2 + 2.8 — config 3's 8192-gate
+        // shard through host buffers: 32.2 ms with the balanced cut, 30.2 ms on one stream (profiles/r04/)
+        if (c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general) {
+            const int64_t resident = 8 * (int64_t)c->cu_count;
+            int64_t total = 0;
+            for (int64_t g = 0; g < B; g++) total += opcodes[g] == TFHE_GATE_MUX ? 2 : op_has_b(opcodes[g]) ? 1 : 0;
+            const int64_t target = (total / 2 + resident / 2) / resident * resident;       // multiple of a round nearest to the middle
+            if (target > 0 && target < total && total % resident != 0) {
+                int64_t cum = 0, g = 0;
+                while (g < B && cum < target) { cum += opcodes[g] == TFHE_GATE_MUX ? 2 : op_has_b(opcodes[g]) ? 1 : 0; g++; }
+                if (cum == target || cum == target + 1) bounds[1] = g;      // (a MUX may straddle the boundary by one rotation)
+            }
+        }
         if (bounds[1] > 0 && bounds[1] < B) {
             const int32_t rct = ensure_twin(c);
             if (rct) return rct;

@@ -108,6 +108,9 @@ def main():
         rng = np.random.default_rng(123)
         sk, ck = tfhe.make_key_pair(rng, tfhe.tfhe_parameters_80())
         eng = ck.engine(0)
+        for name, value in OPTIONS:
+            if name != "pipeline_min" or ("pipeline_min=%d" % value) in a.set:   # (the tool's own pipeline_min=-1 default does not apply to this configuration)
+                eng.set_option(name, value)
         B = a.gates or 8192              # one GPU's shard of 65536 / 8
         names = ["NAND", "AND", "OR", "XOR", "MUX"]
         mrng = np.random.default_rng(789)
