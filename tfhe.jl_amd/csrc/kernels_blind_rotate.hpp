@@ -1328,31 +1328,37 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = ps[r * 64 + lane];
             // g_r8 = (a~_r +- conj(kappa)^r b~_r) conj(c_r8), r8 = r + 4 h; coefficient t + 64 r8 = Re g, + 512: -Im g
-            static_for<0, 4>([&](auto rc) {
-                constexpr int R = decltype(rc)::value;
-                const cplx al = h ? o[R] : own[R], be = h ? own[R] : o[R];
-                cplx kb;                              // conj(kappa)^R * be
-                if (R == 0) kb = be;
-                else if (R == 1) kb = mk((be.x - be.y) * rs, (be.x + be.y) * rs);
-                else if (R == 2) kb = mk(-be.y, be.x);
-                else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
-                const cplx wq = h ? csub(al, kb) : cadd(al, kb);
-                const double re0 = wq.x * twc(R) - wq.y * tws(R), im0 = wq.x * tws(R) + wq.y * twc(R);           // conj(c_R)
-                const double re4 = wq.x * twc(R + 4) - wq.y * tws(R + 4), im4 = wq.x * tws(R + 4) + wq.y * twc(R + 4);
-                const double re = h ? re4 : re0, im = h ? im4 : im0;
-                if (MARGIN) {
-                    const double fa = frac_dist(re), fb = frac_dist(im);
-                    worst = fa > worst ? fa : worst;
-                    worst = fb > worst ? fb : worst;
-                }
-                const int jlo = lane + 64 * (R + 4 * h);
-                const int32_t clo = h ? cur[R + 4] : cur[R], chi = h ? cur[R + 12] : cur[R + 8];     // read at rotate time; nobody else writes them
-                const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
-                const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
-                acc_lds[kMir + jlo] = nlo;
-                acc_lds[kMir + jlo + kM] = nhi;
-                if (h == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
-            });
+            // (one copy of this per half, chosen by a scalar branch: with h a run-time value both twists were computed and one
+            //  selected — 8 FP64 operations and 8 selects per point instead of 4 and none)
+            auto recombine = [&](auto hc) {
+                constexpr int H = decltype(hc)::value;
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int R = decltype(rc)::value;
+                    const cplx al = H ? o[R] : own[R], be = H ? own[R] : o[R];
+                    cplx kb;                              // conj(kappa)^R * be
+                    if (R == 0) kb = be;
+                    else if (R == 1) kb = mk((be.x - be.y) * rs, (be.x + be.y) * rs);
+                    else if (R == 2) kb = mk(-be.y, be.x);
+                    else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
+                    const cplx wq = H ? csub(al, kb) : cadd(al, kb);
+                    constexpr int R8 = R + 4 * H;
+                    const double re = wq.x * twc(R8) - wq.y * tws(R8), im = wq.x * tws(R8) + wq.y * twc(R8);           // conj(c_R8)
+                    if (MARGIN) {
+                        const double fa = frac_dist(re), fb = frac_dist(im);
+                        worst = fa > worst ? fa : worst;
+                        worst = fb > worst ? fb : worst;
+                    }
+                    const int jlo = lane + 64 * R8;
+                    const int32_t clo = cur[R8], chi = cur[R8 + 8];     // read at rotate time; nobody else writes them
+                    const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
+                    const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+                    acc_lds[kMir + jlo] = nlo;
+                    acc_lds[kMir + jlo + kM] = nhi;
+                    if (H == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
+                });
+            };
+            if (h) recombine(std::integral_constant<int, 1>{});
+            else recombine(std::integral_constant<int, 0>{});
         }
         STAMP(8);
         __syncthreads();     // the updated polynomials are visible to every wave's rotation
