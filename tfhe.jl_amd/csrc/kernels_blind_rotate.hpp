@@ -1518,6 +1518,7 @@ __host__ __device__ constexpr double cos_pi32(int k)    // cos(k pi / 32)
 }
 __host__ __device__ constexpr double sin_pi32(int k) { return cos_pi32(k - 16); }
 
+
 struct Br2048Args {
     DiagArgs diag;
     const int32_t *bara;   // [R][n+1]
@@ -1656,19 +1657,22 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 
     int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
     wave_priority_begin(P.prio_steps);
+    // One copy of the step loop per wave half, chosen ONCE by a scalar branch: the per-half constants of the radix-2 split (the
+    // twist angles, the sign of kappa, which block is handed over) are then compile-time constants.  Round 3 selected them per
+    // lane (v_cndmask on every constant: faster than scalar branches around every use, 44.6 vs 46.5 ms); with the whole loop
+    // duplicated there is nothing to select (blind_rotate_kernel_h2's recombination gained 6 % from the same change).
+    auto steps = [&](auto wvc) {
+    constexpr int WV = decltype(wvc)::value;
+    constexpr bool wave1 = WV != 0;
+    constexpr double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         wave_priority_step(i, P.prio_steps);
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);
-        // (lane and wave half rebuilt per step: what is derived from them is recomputed here instead of living, and being spilled,
-        //  across the whole loop.  The half as a PER-LANE value on purpose: the per-wave constants of the radix-2 split are then
-        //  selected per lane instead of by scalar branches — round 3, one device, config 4b: 44.6 ms against 46.5 ms)
+        // (the lane rebuilt per step: what is derived from it is recomputed here instead of living, and being spilled, across
+        //  the whole loop)
         const int lane = lane_id_fresh();
-        int wvv;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(wvv) : "s"(wv));
-        const bool wave1 = wvv != 0;
-        const double sg = wave1 ? -0.70710678118654752440 : 0.70710678118654752440;
         const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + wv * kM;      // (scalar; the lane is added per transform)
         cplx out[K1][8];
 #pragma unroll
@@ -1755,6 +1759,9 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
         WAVE_LDS_FENCE();       // (no barrier: only this wave reads or writes acc_own, and the buffer just read is this wave's again)
         STAMP(8);
     }
+    };
+    if (wv) steps(std::integral_constant<int, 1>{});
+    else steps(std::integral_constant<int, 0>{});
     STAMP_FLUSH(P.diag, wib);
     __syncthreads();            // extraction reads both polynomials
 
