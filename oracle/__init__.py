@@ -13,7 +13,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libtfhe_oracle.so")
+# TFHE_ORACLE_SO: another build of the same source (the AddressSanitizer / UBSan build of `make -C oracle sanitize`,
+# tests/test_oracle_sanitized.py)
+_SO = os.environ.get("TFHE_ORACLE_SO") or os.path.join(_HERE, "libtfhe_oracle.so")
 
 # opcode numbering shared with include/tfhe_mi355x.h
 OPS = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
