@@ -68,8 +68,12 @@ def host_sim():
     so = os.path.join(d, "libsim_br.so")
     src = os.path.join(d, "sim_br.cpp")
     hdr = os.path.join(ROOT, "tfhe.jl_amd", "csrc", "br_core.hpp")
+    san = os.environ.get("TFHE_HOST_SIM_SANITIZE") == "1"       # tests/test_oracle_sanitized.py: ASan + UBSan build, runtimes preloaded
+    if san:
+        so = os.path.join(d, "libsim_br_san.so")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if san else ["-O2"]
+        subprocess.check_call(["g++", *flags, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     lib = C.CDLL(so)
     lib.sim_blind_rotate.restype = C.c_double
     lib.sim_blind_rotate_v3.restype = C.c_double
