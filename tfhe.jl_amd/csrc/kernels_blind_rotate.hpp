@@ -1210,9 +1210,50 @@ __device__ __forceinline__ void fft256_inv(int lane, cplx (&x)[4], const H2LaneT
     dft4<true>(x);
 }
 
+// Recombination of the two inverse half-transforms of one output polynomial by the owner of half H (own: its half, o: the partner's):
+//   g_r8 = (a~_r +- conj(kappa)^r b~_r) conj(c_r8), r8 = r + 4 H; coefficient t + 64 r8 = Re g, + 512: -Im g,
+// rounded and added to the coefficients read at rotate time (cur), written back with the mirror block (rotate_sub3).
+// H is a template argument: with the half a run-time value both twists were computed and one selected — 8 FP64 operations and
+// 8 selects per point instead of 4 and none (1.710 -> 1.613 ms per single gate).
+template <int H, bool MARGIN>
+__device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], const cplx (&o)[4], const int32_t (&cur)[16], int32_t *acc_lds, double &worst)
+{
+    const double rs = 0.70710678118654752440;
+    static_for<0, 4>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const cplx al = H ? o[R] : own[R], be = H ? own[R] : o[R];
+        cplx kb;                              // conj(kappa)^R * be
+        if (R == 0) kb = be;
+        else if (R == 1) kb = mk((be.x - be.y) * rs, (be.x + be.y) * rs);
+        else if (R == 2) kb = mk(-be.y, be.x);
+        else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
+        const cplx wq = H ? csub(al, kb) : cadd(al, kb);
+        constexpr int R8 = R + 4 * H;
+        const double re = wq.x * twc(R8) - wq.y * tws(R8), im = wq.x * tws(R8) + wq.y * twc(R8);           // conj(c_R8)
+        if (MARGIN) {
+            const double fa = frac_dist(re), fb = frac_dist(im);
+            worst = fa > worst ? fa : worst;
+            worst = fb > worst ? fb : worst;
+        }
+        const int jlo = lane + 64 * R8;
+        const int32_t clo = cur[R8], chi = cur[R8 + 8];     // read at rotate time; nobody else writes them
+        const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
+        const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+        acc_lds[kMir + jlo] = nlo;
+        acc_lds[kMir + jlo + kM] = nhi;
+        if (H == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
+    });
+}
+
 // (Measured dead end: letting the two waves of a transform each rotate and decompose only half of the lane's points and
 //  swap the twisted points through LDS saves a quarter of the forward instructions but costs a fourth barrier: 1.76 ms
-//  against 1.70 ms per gate.)
+//  against 1.70 ms per gate.  Round 4, also measured and removed: FOUR waves per rotation, wave (c, h) running half h of all
+//  L digit transforms of polynomial c side by side, stage by stage, so that one transform's LDS round trip overlaps the other's
+//  butterflies — two waves rotate a polynomial instead of 2 L, the digits' partial products are summed in registers, one
+//  hand-off per wave instead of L + 1, every wave busy through the whole step on a SIMD of its own; bit-identical, 222
+//  registers, and slower: 1.75-1.79 against 1.60-1.62 ms (l = 2), 3.02 against 2.48 ms (l = 3).  A lone wave issues an FP64
+//  instruction every ~6 cycles whatever its instruction-level parallelism; the second wave on the SIMD is
+//  what fills the gaps, and the forward phase of this kernel has it.)
 template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H2Tables HT)
 {
@@ -1327,38 +1368,9 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
             cplx o[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = ps[r * 64 + lane];
-            // g_r8 = (a~_r +- conj(kappa)^r b~_r) conj(c_r8), r8 = r + 4 h; coefficient t + 64 r8 = Re g, + 512: -Im g
-            // (one copy of this per half, chosen by a scalar branch: with h a run-time value both twists were computed and one
-            //  selected — 8 FP64 operations and 8 selects per point instead of 4 and none)
-            auto recombine = [&](auto hc) {
-                constexpr int H = decltype(hc)::value;
-                static_for<0, 4>([&](auto rc) {
-                    constexpr int R = decltype(rc)::value;
-                    const cplx al = H ? o[R] : own[R], be = H ? own[R] : o[R];
-                    cplx kb;                              // conj(kappa)^R * be
-                    if (R == 0) kb = be;
-                    else if (R == 1) kb = mk((be.x - be.y) * rs, (be.x + be.y) * rs);
-                    else if (R == 2) kb = mk(-be.y, be.x);
-                    else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
-                    const cplx wq = H ? csub(al, kb) : cadd(al, kb);
-                    constexpr int R8 = R + 4 * H;
-                    const double re = wq.x * twc(R8) - wq.y * tws(R8), im = wq.x * tws(R8) + wq.y * twc(R8);           // conj(c_R8)
-                    if (MARGIN) {
-                        const double fa = frac_dist(re), fb = frac_dist(im);
-                        worst = fa > worst ? fa : worst;
-                        worst = fb > worst ? fb : worst;
-                    }
-                    const int jlo = lane + 64 * R8;
-                    const int32_t clo = cur[R8], chi = cur[R8 + 8];     // read at rotate time; nobody else writes them
-                    const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
-                    const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
-                    acc_lds[kMir + jlo] = nlo;
-                    acc_lds[kMir + jlo + kM] = nhi;
-                    if (H == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
-                });
-            };
-            if (h) recombine(std::integral_constant<int, 1>{});
-            else recombine(std::integral_constant<int, 0>{});
+            // (one copy of the recombination per half, chosen by a scalar branch: h2_recombine)
+            if (h) h2_recombine<1, MARGIN>(lane, own, o, cur, acc_lds, worst);
+            else h2_recombine<0, MARGIN>(lane, own, o, cur, acc_lds, worst);
         }
         STAMP(8);
         __syncthreads();     // the updated polynomials are visible to every wave's rotation
