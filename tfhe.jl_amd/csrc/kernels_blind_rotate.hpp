@@ -1253,7 +1253,9 @@ __device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], con
 //  hand-off per wave instead of L + 1, every wave busy through the whole step on a SIMD of its own; bit-identical, 222
 //  registers, and slower: 1.75-1.79 against 1.60-1.62 ms (l = 2), 3.02 against 2.48 ms (l = 3).  A lone wave issues an FP64
 //  instruction every ~6 cycles whatever its instruction-level parallelism; the second wave on the SIMD is
-//  what fills the gaps, and the forward phase of this kernel has it.)
+//  what fills the gaps, and the forward phase of this kernel has it.  Giving the second digit's wave half of the owner's
+//  recombination (it shares the owner's SIMD and idles through the inverse phase): 1.615-1.621 against 1.596-1.628 ms, l = 3:
+//  2.45 against 2.47-2.48 ms — inside the spread, not kept.)
 template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H2Tables HT)
 {
