@@ -298,7 +298,10 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 /* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
  * "measure_margin", "mk_general", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
  * csrc/tfhe_engine.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
- * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise). */
+ * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise).
+ * "timing_events" (default 1): 0 makes the gate entry points record no per-phase timing events — each record keeps the stream's
+ * next kernel waiting ~5 us, which a level of a narrow circuit (six short operations around one single-rotation kernel) feels;
+ * tfhe_last_timing_ms / tfhe_timing_history_ms then have nothing to report for those calls (TFHE_ERR_STATE). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

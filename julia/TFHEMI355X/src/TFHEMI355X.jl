@@ -125,6 +125,9 @@ mutable struct GpuCloudKey
         ctx = create_context(p, devices)
         gck = new(p, ctx, Int(wires), false, 0, Int32[], Vector{Vector{Int32}}())
         finalizer(destroy!, gck)
+        # no per-phase timing events: nothing in this module reads them, and every record keeps the stream's next kernel
+        # waiting ~5 us (six per circuit level; include/tfhe_mi355x.h, tfhe_set_option)
+        check(ctx, ccall((:tfhe_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx, "timing_events", Int64(0)))
         gck
     end
 end

@@ -62,6 +62,65 @@ def test_tutorial_circuit_on_device(tfhe, orc, keys80):
 
 
 @pytest.mark.gpu
+def test_levels_without_timing_events_and_across_streams(tfhe, keys80):
+    """`timing_events` = 0 (what Circuit.run sets while its levels run): same words, nothing for tfhe_last_timing_ms to report;
+    and the ordering a call owes the previous one when the caller changes streams between calls (the context's own stream records
+    its end-of-call event only on demand)."""
+    K = keys80
+    eng = K.ck.engine(0)
+    rng = np.random.default_rng(5)
+    B = 40
+    x, y = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(2)]
+    ops = np.full(B, tfhe.OPCODES["NAND"], np.uint8)
+    want = eng.gates(ops, x, y)
+    assert eng.last_timing_ms(0) > 0.0
+    idx = np.arange(B, dtype=np.int32)
+    eng.wires_alloc(3 * B)
+    eng.wires_upload(0, np.concatenate([x, y]))
+    eng.set_option("timing_events", 0)
+    try:
+        eng.gates_level(ops, idx, idx + B, None, idx + 2 * B)
+        assert np.array_equal(eng.wires_download(2 * B, B), want)
+        with pytest.raises(tfhe.EngineError):
+            eng.last_timing_ms(0)
+    finally:
+        eng.set_option("timing_events", 1)
+    # own stream -> a caller's stream -> own stream, each call consuming the previous one's result through the shared workspaces
+    # (device buffers and the second stream straight from the HIP runtime the engine already loaded: no second runtime in the process)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    nbytes = x.nbytes
+
+    def dev(host=None):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+        if host is not None:
+            assert hip.hipMemcpy(p, host.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), 1) == 0      # hipMemcpyHostToDevice
+        return p
+
+    def host_of(p):
+        out = np.empty_like(x)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), p, C.c_size_t(nbytes), 2) == 0           # hipMemcpyDeviceToHost
+        return out
+
+    dx, dy, d1, d2 = dev(x), dev(y), dev(), dev()
+    side = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(side)) == 0
+    try:
+        eng.gates_dev(ops, dx.value, dy.value, 0, d1.value, B)                          # own stream
+        eng.gates_dev(ops, d1.value, dy.value, 0, d2.value, B, stream=side.value)       # the caller's: must wait for the first
+        eng.gates_dev(ops, d2.value, dx.value, 0, d1.value, B)                          # own stream again: must wait for the second
+        assert hip.hipDeviceSynchronize() == 0
+        step2 = eng.gates(ops, want, y)
+        assert np.array_equal(host_of(d2), step2)
+        assert np.array_equal(host_of(d1), eng.gates(ops, step2, x))
+    finally:
+        hip.hipStreamDestroy(side)
+        for p in (dx, dy, d1, d2):
+            hip.hipFree(p)
+
+
+@pytest.mark.gpu
 def test_log_depth_minimum_circuit_on_device(tfhe, orc, keys80):
     """examples/tutorial.py, log_depth=True: the comparator ripple of examples/tutorial.jl:42-56 replaced by a reduction tree
     (7 levels instead of 18); same function, checked against the oracle word for word and against min() on decrypted bits."""

@@ -79,6 +79,7 @@ struct tfhe_ctx {
     hipEvent_t done_ev = nullptr;        // recorded at the end of every batch call: the workspaces are shared, so the next
     bool done_pending = false;           // call makes ITS stream wait for this event (no foreign stream handle is kept)
     bool timing_valid = false;
+    bool own_pending = false;    // work queued on the context's own stream since the last done_ev (leave_stream)
     int64_t last_rotations = 0;
     std::string last_kernel;             // blind-rotate kernel instantiation the last batch call launched
     int ks_slices_large = 2;     // K-split of the MFMA keyswitch for large batches (tfhe_set_option("ks_slices", 1|2|4))
@@ -88,6 +89,7 @@ struct tfhe_ctx {
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
     int br_general = 0;          // tfhe_set_option("br_general", 1): every single-key blind rotation on blind_rotate_kernel_general (cross-check of the specialised kernels)
     int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels in a second launch (launch_blind_rotate)
+    int timing_events = 1;       // 0: the gate entry points record no timing events (tfhe_last_timing_ms then has nothing to report)
     int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
                                  //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
                                  //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
@@ -996,6 +998,12 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
 // `s` wait for that event orders the two without blocking the host and without keeping the caller's stream handle.
 static int32_t enter_stream(tfhe_ctx *c, hipStream_t s)
 {
+    if (c->own_pending && s != c->stream) {
+        // the previous call ran on the context's own stream and recorded nothing (leave_stream): record now, for this caller's stream
+        HIP_TRY(c, hipEventRecord(c->done_ev, c->stream));
+        c->own_pending = false;
+        c->done_pending = true;
+    }
     if (!c->done_pending) return TFHE_OK;
     // Already finished (the common case for callers that synchronise between calls): nothing to order, and the event is not
     // handed to the runtime again — the stream it was recorded on may have been destroyed by its owner since.
@@ -1007,6 +1015,11 @@ static int32_t enter_stream(tfhe_ctx *c, hipStream_t s)
 }
 static int32_t leave_stream(tfhe_ctx *c, hipStream_t s)
 {
+    // Calls that follow one another on the context's own stream are ordered by the stream; the event exists for a caller that
+    // changes streams between calls, and is then recorded on demand (enter_stream).  (An event record keeps the next kernel of the
+    // stream waiting ~5 us: six of them per circuit level were 1.3 % of the tutorial circuit.)
+    if (s == c->stream) { c->own_pending = true; return TFHE_OK; }
+    c->own_pending = false;
     HIP_TRY(c, hipEventRecord(c->done_ev, s));
     c->done_pending = true;
     return TFHE_OK;
@@ -1109,8 +1122,9 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     const uint8_t *d_kind = (const uint8_t *)(d_td + Tn), *d_top = d_kind + R;
 
     const int n = c->P.n, kNn = c->P.k * c->P.N;
+    const bool no_ev = !c->timing_events;       // option "timing_events": every event record costs the stream ~5 us between two kernels
     next_timing_slot(c);
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[0], s));
     if (R > 0) {
         HIP_TRY(c, c->bara.reserve(R * (size_t)(n + 1) * 4));
         HIP_TRY(c, c->ext.reserve(R * (size_t)(kNn + 1) * 4));
@@ -1118,24 +1132,24 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
                            (int32_t *)c->bara.p, n, ilog2i(2 * c->P.N));
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[1], s));
     if (R > 0) {
         rc = launch_blind_rotate(c, R, (int32_t)(1u << 29), s);   // mu = encode_message(1, 8), gates.jl:17
         if (rc) return rc;
     } else {
         c->diag_rows = 0;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[2], s));
     if (G > 0) {
         rc = launch_keyswitch(c, G, d_e0, d_e1, d_dst, (const int32_t *)c->ext.p, d_out, s);
         if (rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[3], s));
     if (Tn > 0) {
         hipLaunchKernelGGL(trivial_gates_kernel, dim3((unsigned)Tn), dim3(256), 0, s, d_in0, d_ts, d_td, d_top, d_out, n);
         HIP_TRY(c, hipGetLastError());
     }
-    commit_timing_slot(c);
+    if (!no_ev) commit_timing_slot(c);
     c->last_rotations = (int64_t)R;
     return leave_stream(c, s);
 }
@@ -1406,7 +1420,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
+    t->br_tiny = c->br_tiny; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
     return TFHE_OK;
 }
 
@@ -2262,6 +2276,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
+    if (!strcmp(name, "timing_events")) { c->timing_events = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
     if (!strcmp(name, "level_split_min")) return TFHE_OK;      // (meaningful on a multi-device context only)
