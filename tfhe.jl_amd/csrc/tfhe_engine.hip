@@ -344,6 +344,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->twin) { tfhe_ctx_destroy(c->twin); c->twin = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->done_pending && c->done_ev) (void)hipEventSynchronize(c->done_ev);      // a call still running on a caller's stream
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->borrows_keys) c->d_bk = nullptr, c->d_ks = nullptr, c->d_ksp = nullptr, c->d_ks4 = nullptr;      // the owner frees them
     if (c->d_bk) (void)hipFree(c->d_bk);
@@ -466,6 +467,8 @@ static int32_t check_key_source(tfhe_ctx *c, const void *p, const char *who)
 static void quiesce(tfhe_ctx *c)
 {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->done_pending) { (void)hipEventSynchronize(c->done_ev); c->done_pending = false; }      // a call still running on a caller's stream
+    c->own_pending = false;
     if (c->twin && c->twin->stream) (void)hipStreamSynchronize(c->twin->stream);
     c->slot_busy[0] = c->slot_busy[1] = false;
     if (c->twin) {
