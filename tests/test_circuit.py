@@ -62,6 +62,28 @@ def test_tutorial_circuit_on_device(tfhe, orc, keys80):
 
 
 @pytest.mark.gpu
+def test_circuit_on_a_batch_of_input_sets(tfhe, keys80):
+    """Circuit.run_batch: M instances of the tutorial circuit, every level one call over all instances — word for word what
+    Circuit.run gives for each instance alone (every gate is a function of its own operands only), and the right minima."""
+    K = keys80
+    c = tutorial_min_circuit(tfhe, 8)
+    rng = np.random.default_rng(11)
+    pairs = [(int(rng.integers(0, 256)), int(rng.integers(0, 256))) for _ in range(5)] + [(7, 7)]
+    encs = []
+    for x, y in pairs:
+        bits = [(x >> i) & 1 == 1 for i in range(8)] + [(y >> i) & 1 == 1 for i in range(8)]
+        encs.append(tfhe.encrypt(K.rng, K.sk, bits))
+    got = c.run_batch(K.ck, encs)
+    assert got.shape == (len(pairs), 8, K.params.lwe_size + 1)
+    for i, (x, y) in enumerate(pairs):
+        assert np.array_equal(got[i], c.run(K.ck, encs[i]).data), i
+        assert sum(int(v) << j for j, v in enumerate(tfhe.decrypt(K.sk, tfhe.LweSampleArray(got[i])))) == min(x, y)
+    assert c.run_batch(K.ck, np.zeros((0, 16, K.params.lwe_size + 1), np.int32)).shape == (0, 8, K.params.lwe_size + 1)
+    with pytest.raises(ValueError):
+        c.run_batch(K.ck, np.zeros((2, 3, K.params.lwe_size + 1), np.int32))
+
+
+@pytest.mark.gpu
 def test_levels_without_timing_events_and_across_streams(tfhe, keys80):
     """`timing_events` = 0 (what Circuit.run sets while its levels run): same words, nothing for tfhe_last_timing_ms to report;
     and the ordering a call owes the previous one when the caller changes streams between calls (the context's own stream records

@@ -114,3 +114,33 @@ class Circuit:
             return LweSampleArray(eng.wires_gather(self._outputs))     # one device gather + one copy for all outputs
         finally:
             eng.set_option("timing_events", 1)
+
+    def run_batch(self, ck, inputs, device=0):
+        """The same circuit on M independent input sets at once: inputs int32 [M][n_inputs][n+1] (or a list of M LweSampleArrays),
+        result int32 [M][n_outputs][n+1].  Every level becomes ONE tfhe_gates_level call over the M instances' gates — a level of
+        a narrow circuit costs one single-rotation latency whether it holds 1 gate or 256 (one blind rotation per CU), so M <= 256 /
+        (rotations of the widest level) instances cost what one does; beyond that the levels run at batch throughput.
+        Wire w of instance i is row w * M + i of the wire table: the inputs go up as one block, the outputs come down as one gather."""
+        eng = ck.engine(device)
+        if isinstance(inputs, (list, tuple)):
+            inputs = np.stack([x.data if isinstance(x, LweSampleArray) else np.asarray(x, np.int32) for x in inputs])
+        m = np.ascontiguousarray(inputs, dtype=np.int32)
+        if m.ndim != 3 or m.shape[1] != self._n_inputs:
+            raise ValueError(f"inputs must be [M][{self._n_inputs}][n+1], got {m.shape}")
+        M = m.shape[0]
+        if M == 0:
+            return np.zeros((0, len(self._outputs), m.shape[2]), np.int32)
+        eng.wires_alloc(self.num_wires * M)
+        if self._n_inputs:
+            eng.wires_upload(0, np.ascontiguousarray(m.transpose(1, 0, 2)).reshape(self._n_inputs * M, -1))
+        inst = np.arange(M, dtype=np.int32)
+        spread = lambda w: (w[:, None] * M + inst[None, :]).reshape(-1).astype(np.int32)      # wire ids -> rows, instance fastest
+        eng.set_option("timing_events", 0)
+        try:
+            for ops, a, b, c, out in self.level_arrays():
+                eng.gates_level(np.repeat(ops, M), spread(a), spread(b), spread(c), spread(out))
+            rows = eng.wires_gather(spread(np.asarray(self._outputs, np.int32)))
+        finally:
+            eng.set_option("timing_events", 1)
+        return np.ascontiguousarray(rows.reshape(len(self._outputs), M, -1).transpose(1, 0, 2))
+

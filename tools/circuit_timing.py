@@ -21,3 +21,10 @@ tree = encrypted_minimum_circuit(16, log_depth=True)
 for it in range(3):
     t0 = time.perf_counter(); out = tree.run(ck, inputs); dt = time.perf_counter() - t0
     print(f"log-depth variant ({len(tree.levels())} levels, {sum(len(l) for l in tree.levels())} gates) run {it}: {dt*1e3:.1f} ms -> {bits_to_int(tfhe.decrypt(sk, out))}")
+# the same circuit on many input sets at once (Circuit.run_batch): every level is one call over all instances
+for M in (64, 128, 1024):
+    many = np.broadcast_to(inputs.data, (M,) + inputs.data.shape).copy()
+    circ.run_batch(ck, many[:2])
+    t0 = time.perf_counter(); res = circ.run_batch(ck, many); dt = time.perf_counter() - t0
+    ok = all(bits_to_int(tfhe.decrypt(sk, tfhe.LweSampleArray(res[i]))) == 42 for i in (0, M // 2, M - 1))
+    print(f"{M} instances of the 18-level circuit in one run_batch: {dt*1e3:.1f} ms = {dt*1e3/M:.3f} ms per instance ({'ok' if ok else 'WRONG'})")
