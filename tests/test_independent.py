@@ -358,7 +358,7 @@ def _mk_setup(tfhe, parties, l, beta, n, seed):
     return p, sks, ck, xs, ys, want
 
 
-MK_CASES = [(2, 4, 7, 6), (4, 5, 6, 3)]      # (parties, l, beta, n): mktfhe_parameters_2party / _4party gadget shapes (mk_api.jl:4-22)
+MK_CASES = [(2, 4, 7, 6), (4, 5, 6, 3), (8, 8, 4, 2)]      # (parties, l, beta, n): mktfhe_parameters_2party / _4party / _8party gadget shapes (mk_api.jl:4-34)
 
 
 @pytest.mark.parametrize("parties,l,beta,n", MK_CASES)
@@ -375,9 +375,9 @@ def test_oracle_mk_equals_schoolbook(orc, tfhe, parties, l, beta, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("parties,l,beta,n", MK_CASES)
 def test_gpu_mk_equals_schoolbook(tfhe, parties, l, beta, n):
-    """tfhe_mk_gate_nand_batch (mk_blind_rotate_kernel_w2<4> / g2<4,5,acc=lds>) against the multi-key schoolbook — no oracle."""
+    """tfhe_mk_gate_nand_batch (mk_blind_rotate_kernel_w2<4> / g2<4,5,acc=lds> / g2<8,8>) against the multi-key schoolbook — no oracle."""
     p, sks, ck, xs, ys, want = _mk_setup(tfhe, parties, l, beta, n, 400 + parties)
     eng = ck.engine(0)
     assert np.array_equal(eng.mk_gate_nand(xs, ys), want)
-    assert eng.last_kernel_name() == ("mk_blind_rotate_kernel_w2<4>" if parties == 2 else "mk_blind_rotate_kernel_g2<4,5,acc=lds>")
+    assert eng.last_kernel_name() == {2: "mk_blind_rotate_kernel_w2<4>", 4: "mk_blind_rotate_kernel_g2<4,5,acc=lds>", 8: "mk_blind_rotate_kernel_g2<8,8>"}[parties]
     ck.close()
