@@ -283,6 +283,23 @@ def test_gpu_equals_schoolbook_full_size(tfhe, keys80, keys128, which):
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bits[0] & bits[1]))
 
 
+@pytest.mark.gpu
+def test_gpu_equals_schoolbook_full_size_n2048(tfhe, orc):
+    """BASELINE config 4b at full size (synthetic N = 2048, n = 630, l = 3, beta = 7): one NAND gate through tfhe_gates_batch
+    (blind_rotate_kernel_n2048x) against the schoolbook restatement — no oracle call in the comparison (630 CMUX steps of twelve
+    2048-coefficient integer products: about a minute of numpy convolutions)."""
+    from conftest import KeySet
+    from test_oracle import synthetic_2048
+    K = KeySet(tfhe, orc, synthetic_2048(tfhe), seed=2048)
+    x, y, bits, want = _full_size_case(tfhe, K, 1)
+    eng = K.ck.engine(0)
+    got = eng.gates(np.zeros(1, np.uint8), x, y)
+    assert eng.last_kernel_name().startswith("blind_rotate_kernel_n2048x<3")
+    assert np.array_equal(got, want)
+    assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bits[0] & bits[1]))
+    K.ck.close()
+
+
 # ---- (a'') multi-key (config 5): mk_gate_nand in exact integer arithmetic ------------------------------------------------------
 class MKSchoolbook(Schoolbook):
     """mk_gate_nand (mk_gates.jl:7-12) -> mk_bootstrap (mk_internals.jl:464-515) -> mk_tgsw_extern_mul (:348-391) ->
