@@ -398,3 +398,25 @@ def test_gpu_mk_equals_schoolbook(tfhe, parties, l, beta, n):
     assert np.array_equal(eng.mk_gate_nand(xs, ys), want)
     assert eng.last_kernel_name() == {2: "mk_blind_rotate_kernel_w2<4>", 4: "mk_blind_rotate_kernel_g2<4,5,acc=lds>", 8: "mk_blind_rotate_kernel_g2<8,8>"}[parties]
     ck.close()
+
+
+@pytest.mark.gpu
+def test_gpu_mk_equals_schoolbook_full_size_2party(tfhe):
+    """BASELINE config 5 at full size (mktfhe_parameters_2party, mk_api.jl:4-14): one 2-party NAND through
+    tfhe_mk_gate_nand_batch (mk_blind_rotate_kernel_w2<4>) against the multi-key schoolbook — no oracle (2 x n CMUX steps of
+    28 integer products: under a minute of numpy convolutions)."""
+    p = tfhe.mktfhe_parameters_2party
+    rng = np.random.default_rng(52)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(2)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    sb = MKSchoolbook(p.lwe_size, p.tlwe_polynomial_degree, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base,
+                      2, ck.bootstrap_key, ck.keyswitch_key)
+    xs, ys = tfhe.mk_encrypt(rng, sks, [True]), tfhe.mk_encrypt(rng, sks, [True])
+    want = sb.mk_gate_nand(xs[0], ys[0]).astype(np.int32)
+    eng = ck.engine(0)
+    got = eng.mk_gate_nand(xs, ys)
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w2<4>"
+    assert np.array_equal(got[0], want)
+    ck.close()
+
