@@ -180,6 +180,58 @@ def test_gpu_equals_schoolbook(tfhe, N, k, l, beta, n):
     ck.close()
 
 
+# ---- (a-gates) every gate's affine prologue + MUX's two rotations, restated from gates.jl ----------------------------------------
+# result = c/8-or-/4 constant on b  +  sx * x  +  sy * y  (then one bootstrap with mu = 1/8); gates.jl:15-18 (NAND), :27-30 (OR),
+# :39-42 (AND), :51-54 (XOR: (x + y) * 2, every word wraps), :63-66 (XNOR), :100-103 (NOR), :113-116 (ANDNY), :126-129 (ANDYN),
+# :139-142 (ORNY), :152-155 (ORYN)
+_AFFINE = {"NAND": (2**29, -1, -1), "OR": (2**29, 1, 1), "AND": (-2**29, 1, 1), "XOR": (2**30, 2, 2), "XNOR": (-2**30, -2, -2),
+           "NOR": (-2**29, -1, -1), "ANDNY": (-2**29, -1, 1), "ANDYN": (-2**29, 1, -1), "ORNY": (2**29, -1, 1), "ORYN": (2**29, 1, -1)}
+
+
+def schoolbook_gate(sb, name, x, y, z):
+    """One gate of gates.jl on int32 sample rows, every word wrapping (lwe.jl:63-82)."""
+    x, y, z = (np.asarray(v, np.int64) for v in (x, y, z))
+    n = sb.n
+    if name in _AFFINE:
+        const, sx, sy = _AFFINE[name]
+        t = wrap32(sx * x + sy * y)
+        t[n] = wrap32(t[n] + const)
+        return sb.bootstrap(2**29, t)
+    if name == "NOT":                                        # gates.jl:76-79: not bootstrapped
+        return wrap32(-x)
+    if name == "COPY":                                       # (this engine's own opcode: the sample unchanged)
+        return wrap32(x)
+    if name in ("CONST0", "CONST1"):                         # gates.jl:91-93: noiseless trivial sample of -1/8 / +1/8
+        r = np.zeros(n + 1, np.int64)
+        r[n] = 2**29 if name == "CONST1" else -2**29
+        return wrap32(r)
+    assert name == "MUX"                                     # gates.jl:163-177
+    t1 = wrap32(x + y); t1[n] = wrap32(t1[n] - 2**29)        # AND(x, y)
+    t2 = wrap32(-x + z); t2[n] = wrap32(t2[n] - 2**29)       # AND(NOT x, z)
+    u1, u2 = sb.bootstrap_wo_keyswitch(2**29, t1), sb.bootstrap_wo_keyswitch(2**29, t2)
+    t3 = wrap32(u1 + u2); t3[-1] = wrap32(t3[-1] + 2**29)    # OR in the extracted dimension, then ONE keyswitch
+    return sb.keyswitch(t3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,k,l,beta,n", CASES[:3])
+def test_gpu_gates_equal_schoolbook_gates(tfhe, N, k, l, beta, n):
+    """BASELINE config 3's gate mix and every other opcode through tfhe_gates_batch against gates.jl restated above on top of the
+    schoolbook bootstrap — arbitrary input words, no oracle call."""
+    p, rng, sk, ck = _keys(tfhe, N, k, l, beta, n, 1900 + N + k + l)
+    sb = Schoolbook(n, N, k, l, beta, 8, 2, ck.bootstrap_key, ck.keyswitch_key)
+    names = list(tfhe.OPCODES)
+    order = names + ["MUX", "XOR", "NAND"]
+    B = len(order)
+    x, y, z = (rng.integers(-2**31, 2**31, size=(B, n + 1), dtype=np.int64).astype(np.int32) for _ in range(3))
+    ops = np.array([tfhe.OPCODES[nm] for nm in order], np.uint8)
+    want = np.stack([schoolbook_gate(sb, nm, x[g], y[g], z[g]) for g, nm in enumerate(order)]).astype(np.int32)
+    got = ck.engine(0).gates(ops, x, y, z)
+    for g, nm in enumerate(order):
+        assert np.array_equal(got[g], want[g]), nm
+    ck.close()
+
+
 # ---- (b) noiseless KAT with a random mask ---------------------------------------------------------------------------
 def _noiseless_setup(n, N, l, beta, seed):
     """LWE key, binary TLWE key, noiseless TGSW(s_i) rows built here: row (p, j) = (a, a (*) K) + s_i g_p on component j
