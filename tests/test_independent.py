@@ -213,6 +213,24 @@ def schoolbook_gate(sb, name, x, y, z):
     return sb.keyswitch(t3)
 
 
+@pytest.mark.parametrize("N,k,l,beta,n", CASES[:3])
+def test_oracle_gates_equal_schoolbook_gates(orc, tfhe, N, k, l, beta, n):
+    """The oracle's gate layer (all 15 opcodes, arbitrary input words) against gates.jl restated above."""
+    p, rng, sk, ck = _keys(tfhe, N, k, l, beta, n, 1900 + N + k + l)
+    sb = Schoolbook(n, N, k, l, beta, 8, 2, ck.bootstrap_key, ck.keyswitch_key)
+    o = orc.Oracle(n, N, k, l, beta, 8, 2)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    order = list(tfhe.OPCODES) + ["MUX", "XOR", "NAND"]
+    B = len(order)
+    x, y, z = (rng.integers(-2**31, 2**31, size=(B, n + 1), dtype=np.int64).astype(np.int32) for _ in range(3))
+    ops = np.array([tfhe.OPCODES[nm] for nm in order], np.uint8)
+    got = o.gates(ops, x, y, z)
+    for g, nm in enumerate(order):
+        assert np.array_equal(got[g], schoolbook_gate(sb, nm, x[g], y[g], z[g]).astype(np.int32)), nm
+    ck.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,k,l,beta,n", CASES[:3])
 def test_gpu_gates_equal_schoolbook_gates(tfhe, N, k, l, beta, n):
