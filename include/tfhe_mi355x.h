@@ -31,8 +31,10 @@
  * Parameter sets.  The reference validates nothing (SchemeParameters is a positional struct, tlwe_mask_size a free
  * keyword: api.jl:4-21,30,55).  Single key: tfhe_ctx_create accepts N = 1024 or 2048, tlwe_mask_size k <= 4, any
  * bs_decomp_length l with l * bs_log2_base <= 32, lwe_size <= 1023, any keyswitch base / length with t * gamma <= 31.
- * Tuned kernels exist for k <= 2 with l <= 4 at N = 1024 and for k = 1 with l <= 4 at N = 2048 (every shipped set and
- * BASELINE config 4b); everything else runs on blind_rotate_kernel_general — same words, several times slower.
+ * Tuned kernels: N = 1024 with k = 1 and ANY l (instantiated for the shipped l = 2 and 3; the one- and two-waves-per-rotation
+ * kernels also exist with l as a run-time value and serve every other l at the same speed), N = 1024 with k = 2 and l = 2 or 3,
+ * N = 2048 with k = 1 and l = 3 (BASELINE config 4b).  Everything else (k >= 3; k = 2 or N = 2048 with another l; N = 2048
+ * with k >= 2) runs on blind_rotate_kernel_general — same words, about 3.5 times slower.
  * Multi-key: N = 1024, k = 1 (as the reference, mk_internals.jl:89-91), 2..8 parties, l <= 8.  Outside that
  * (N other than 1024 / 2048, k > 4, multi-key at N = 2048): TFHE_ERR_UNSUPPORTED.
  */
@@ -299,7 +301,8 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
  * "measure_margin", "mk_general", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
  * csrc/tfhe_engine.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
  * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise).
- * "timing_events" (default 1): 0 makes the gate entry points record no per-phase timing events — each record keeps the stream's
+ * "br_rt_l" = 1 runs l = 2 / 3 on the run-time-l instantiations as well (they are otherwise used for every other l; a
+ * comparison switch).  "timing_events" (default 1): 0 makes the gate entry points record no per-phase timing events — each record keeps the stream's
  * next kernel waiting ~5 us, which a level of a narrow circuit (six short operations around one single-rotation kernel) feels;
  * tfhe_last_timing_ms / tfhe_timing_history_ms then have nothing to report for those calls (TFHE_ERR_STATE). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);

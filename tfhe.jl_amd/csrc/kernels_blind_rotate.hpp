@@ -115,6 +115,7 @@ struct BrArgs {
     int32_t mu;
     int32_t prio_steps;   // a wave lowers its issue priority 3 -> 2 -> 1 -> 0 over its first prio_steps CMUX steps (wave_priority_* below); 0: never
     int32_t R;            // rotations in the batch
+    int32_t l;            // decomposition length, read by the instantiations with L = 0 (any l at run time)
     int32_t grp_big, grp_q;   // blind_rotate_kernel_k2<.., 7>: workgroups [0, grp_big) hold grp_q + 1 rotations, the others grp_q
 };
 
@@ -235,7 +236,10 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
 #else
     constexpr int KMID = (KPF == 8) ? 4 : 0;
 #endif
-    constexpr int F = K1 * L;
+    // L = 0: the decomposition length is a run-time value (P.l) — the transform loop is rolled and nothing else depends on it —
+    // so ONE instantiation serves every l no shipped parameter set uses at the speed of the tuned ones
+    const int Lr = L ? L : P.l;
+    const int F = K1 * Lr;
     wave_priority_begin(P.prio_steps);
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     if (padding) w = P.R - 1;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
-    const int32_t xormask = gadget_xor_mask(L, beta);
+    const int32_t xormask = gadget_xor_mask(Lr, beta);
 
     cplx tw1f[8];
 #pragma unroll
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     cplx kbuf[16];
     // chunk f of step: key spectra for transform f = (c, p): 16 values per lane (co-major, k2 minor)
     auto key_ptr = [&](int step, int f) {
-        const int c = f / L, p = f % L;
-        return P.bk + (size_t)step * (L * K1 * K1 * kM) + (size_t)(p * K1 + c) * K1 * kM + lane;
+        const int c = f >= Lr, p = f - c * Lr;          // K1 = 2
+        return P.bk + (size_t)step * (Lr * K1 * K1 * kM) + (size_t)(p * K1 + c) * K1 * kM + lane;
     };
     {
         const cplx *kp = key_ptr(0, 0);
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
         int32_t temp[16];
 #pragma unroll 1
         for (int f = 0; f < F; f++) {
-            const int c = f / L, p = f % L;        // component, digit index (0-based)
+            const int c = f >= Lr, p = f - c * Lr;        // component, digit index (0-based); K1 = 2
             if (p == 0) rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
             cplx x[8];
             load_digits2(temp, p + 1, beta, x);
@@ -1039,7 +1043,8 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_w2(BrArgs P)
     if (padding) w = (size_t)P.R - 1;
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
-    const int32_t xormask = gadget_xor_mask(L, beta);
+    const int Lr = L ? L : P.l;                   // L = 0: any decomposition length at run time (see blind_rotate_kernel_v3)
+    const int32_t xormask = gadget_xor_mask(Lr, beta);
 
     cplx tw1f[8];
 #pragma unroll
@@ -1058,7 +1063,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_w2(BrArgs P)
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         // key polys of transform (p, c = wv): [i][p][c][co][8][64]
-        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
+        const cplx *key = P.bk + (size_t)i * (Lr * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
         // Transposition buffers: in step i this wave transforms in buffer (wv ^ i) & 1 and leaves its hand-off there; after
         // the barrier it reads the other wave's hand-off from the other buffer and runs its inverse transform in it — and
         // keeps that buffer for the forward transforms of step i + 1, while the other wave has moved to this one.  One
@@ -1091,7 +1096,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_w2(BrArgs P)
         };
         digit(0, std::true_type{});
 #pragma unroll 1
-        for (int p = 1; p < L; p++) digit(p, std::false_type{});
+        for (int p = 1; p < Lr; p++) digit(p, std::false_type{});
         // hand the other component's partial sum over
         WAVE_LDS_FENCE();
 #pragma unroll

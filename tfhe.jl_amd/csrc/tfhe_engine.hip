@@ -90,6 +90,7 @@ struct tfhe_ctx {
     int br_general = 0;          // tfhe_set_option("br_general", 1): every single-key blind rotation on blind_rotate_kernel_general (cross-check of the specialised kernels)
     int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels in a second launch (launch_blind_rotate)
     int timing_events = 1;       // 0: the gate entry points record no timing events (tfhe_last_timing_ms then has nothing to report)
+    int br_rt_l = 0;             // 1: the run-time-l instantiations (L = 0) even for l = 2, 3 (A/B)
     int64_t br_tiny = -2;        // batches of at most this many rotations split every transform over two waves (-1: never; -2: one per CU =
                                  //  the device's CU count: 1.75 vs 1.93 ms up to 256 rotations at the 80-bit set, 2.6 vs 3.1 ms at the 128-bit set;
                                  //  3.5 vs 2.6 ms at 320 — profiles/r03/r03h2_*);
@@ -688,6 +689,13 @@ static int32_t prepare_diag(tfhe_ctx *c, size_t R, hipStream_t s, DiagArgs &d)
     case 3: LAUNCH(3); break;                                                                                      \
     default: return c->set_err(TFHE_ERR_STATE, "blind rotate: no tuned kernel for bs_l = %d", c->P.bs_l);          \
     }
+// ... the one- and two-waves-per-rotation kernels also exist with the decomposition length as a run-time value (L = 0)
+#define BR_CASES_ANY_L(LAUNCH)                                                                                     \
+    switch (c->br_rt_l ? 0 : c->P.bs_l) {                                                                          \
+    case 2: LAUNCH(2); break;                                                                                      \
+    case 3: LAUNCH(3); break;                                                                                      \
+    default: LAUNCH(0); break;                                                                                     \
+    }
 
 static void name_kernel(tfhe_ctx *c, const char *fmt, ...)
 {
@@ -717,7 +725,8 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
     a.prio_steps = (int32_t)((int64_t)c->P.n * c->br_prio_pct / 100);
     a.R = (int32_t)R;
     const int L = c->P.bs_l;
-    const bool tuned = c->P.N == kN2 ? (c->P.k == 1 && L == 3) : (c->P.k <= 2 && (L == 2 || L == 3));
+    a.l = L;
+    const bool tuned = c->P.N == kN2 ? (c->P.k == 1 && L == 3) : c->P.k == 1 ? true : (c->P.k == 2 && (L == 2 || L == 3));
     if (!tuned || c->br_general) {
         // any (k <= 4, l, N): one wave per rotation, accumulator images in global memory, spectrum accumulators in LDS
         const int K1 = c->P.k + 1, H = c->P.N / kN;
@@ -806,7 +815,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         return TFHE_OK;
     }
     const int64_t tiny = c->br_tiny == -2 ? (int64_t)c->cu_count : c->br_tiny;
-    if (tiny >= 0 && (int64_t)R <= tiny) {
+    if (tiny >= 0 && (int64_t)R <= tiny && (L == 2 || L == 3) && !c->br_rt_l) {      // (4 l waves per rotation: instantiated for the shipped l only)
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
@@ -836,10 +845,11 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, true>), dim3((unsigned)R), dim3(128), ldsw, s, a); \
         else if (pairs) hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false, 2>), dim3((unsigned)((R + 1) / 2)), dim3(256), 2 * ldsw, s, a); \
         else hipLaunchKernelGGL((blind_rotate_kernel_w2<LL, false>), dim3((unsigned)R), dim3(128), ldsw, s, a)
-        BR_CASES(LAUNCH_W2)
+        BR_CASES_ANY_L(LAUNCH_W2)
 #undef LAUNCH_W2
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, pairs ? "blind_rotate_kernel_w2<%d,rw2>" : "blind_rotate_kernel_w2<%d>", L);
+        if ((L == 2 || L == 3) && !c->br_rt_l) name_kernel(c, pairs ? "blind_rotate_kernel_w2<%d,rw2>" : "blind_rotate_kernel_w2<%d>", L);
+        else name_kernel(c, pairs ? "blind_rotate_kernel_w2<0,rw2>(l=%d)" : "blind_rotate_kernel_w2<0>(l=%d)", L);
         return TFHE_OK;
     }
     {
@@ -858,11 +868,12 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         else if (group) LAUNCH_V3_GROUP(LL, false);                                                                \
         else if (dg) hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, true>), dim3((unsigned)R), dim3(64), lds3, s, a);     \
         else hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, false>), dim3((unsigned)R), dim3(64), lds3, s, a)
-        BR_CASES(LAUNCH_V3)
+        BR_CASES_ANY_L(LAUNCH_V3)
 #undef LAUNCH_V3
 #undef LAUNCH_V3_GROUP
         HIP_TRY(c, hipGetLastError());
-        name_kernel(c, group ? "blind_rotate_kernel_v3<%d,8,tw2reg,rw4>" : "blind_rotate_kernel_v3<%d,8,tw2reg>", L);
+        if ((L == 2 || L == 3) && !c->br_rt_l) name_kernel(c, group ? "blind_rotate_kernel_v3<%d,8,tw2reg,rw4>" : "blind_rotate_kernel_v3<%d,8,tw2reg>", L);
+        else name_kernel(c, group ? "blind_rotate_kernel_v3<0,8,tw2reg,rw4>(l=%d)" : "blind_rotate_kernel_v3<0,8,tw2reg>(l=%d)", L);
         return TFHE_OK;
     }
 }
@@ -1423,7 +1434,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_bk = c->d_bk; t->bk_polys = c->bk_polys; t->d_ks = c->d_ks; t->d_ksp = c->d_ksp; t->ks_stride = c->ks_stride;
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
-    t->br_tiny = c->br_tiny; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
+    t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
     return TFHE_OK;
 }
 
@@ -2279,6 +2290,7 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "br_small")) { c->br_small = value; return TFHE_OK; }
     if (!strcmp(name, "br_tiny")) { c->br_tiny = value; return TFHE_OK; }
+    if (!strcmp(name, "br_rt_l")) { c->br_rt_l = value != 0; return TFHE_OK; }
     if (!strcmp(name, "timing_events")) { c->timing_events = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
