@@ -113,6 +113,15 @@ def test_any_decomposition_length_on_the_tuned_kernels(tfhe, orc, l, beta):
     eng.set_option("br_small", 1024)
     eng.set_option("br_general", 1)
     _check(eng, K, x, f"blind_rotate_kernel_general(N=1024,k=1,l={l})", "the general kernel on the same set")
+    eng.set_option("br_general", 0)
+    if l == 4:
+        # a batch of whole rounds + a small tail: the split launch, with the two-wave kernel (not the 4 l-wave one) for the tail
+        big = np.repeat(x[2:3], 2100, axis=0)
+        big[:, 0] += np.arange(2100, dtype=np.int32) << 20
+        idx = [0, 1, 2047, 2048, 2099]
+        got = eng.bootstrap(MU, big, with_keyswitch=False)
+        assert eng.last_kernel_name() == "blind_rotate_kernel_v3<0,8,tw2reg,rw4>(l=4) + blind_rotate_kernel_w2<0>(l=4)", eng.last_kernel_name()
+        assert np.array_equal(got[idx], K.oracle.bootstrap(MU, big[idx], with_keyswitch=False, nthreads=8))
     K.ck.close()
 
 
