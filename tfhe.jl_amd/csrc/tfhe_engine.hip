@@ -938,7 +938,7 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     const bool tuned_l = c->P.bs_l == 2 || c->P.bs_l == 3;
     if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7)) {
         seg = k2_partition(R, (size_t)c->cu_count);
-    } else if (c->br_split && !c->br_general && c->P.N == kN && c->P.k == 1 && tuned_l && c->br_small > 0) {
+    } else if (c->br_split && !c->br_general && c->P.N == kN && c->P.k == 1 && c->br_small > 0) {      // (any l: the run-time-l instantiations)
         const size_t resident = 8 * (size_t)c->cu_count;      // rotations of blind_rotate_kernel_v3 on the chip
         if (R > resident && R % resident > 0 && R % resident <= (size_t)c->br_small) seg = {R - R % resident, R % resident};
     }
