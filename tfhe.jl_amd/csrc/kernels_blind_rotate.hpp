@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     cplx kbuf[16];
     // chunk f of step: key spectra for transform f = (c, p): 16 values per lane (co-major, k2 minor)
     auto key_ptr = [&](int step, int f) {
-        const int c = f >= Lr, p = f - c * Lr;          // K1 = 2
+        const int c = L ? f / (L ? L : 1) : (f >= Lr), p = L ? f % (L ? L : 1) : f - c * Lr;          // (K1 = 2; the templated l keeps its compile-time division)
         return P.bk + (size_t)step * (Lr * K1 * K1 * kM) + (size_t)(p * K1 + c) * K1 * kM + lane;
     };
     {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
         int32_t temp[16];
 #pragma unroll 1
         for (int f = 0; f < F; f++) {
-            const int c = f >= Lr, p = f - c * Lr;        // component, digit index (0-based); K1 = 2
+            const int c = L ? f / (L ? L : 1) : (f >= Lr), p = L ? f % (L ? L : 1) : f - c * Lr;        // component, digit index (0-based)
             if (p == 0) rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
             cplx x[8];
             load_digits2(temp, p + 1, beta, x);
