@@ -108,3 +108,26 @@ def test_bench_single_rank_through_rccl():
                         "--no-cpu-baseline", "--no-diagnostics"], env)
     assert d["n_gpus"] == 1 and d["outputs_decrypt_correctly"] is True and d["gather_matches_local_shard"] is True
     assert d["config"]["result_gather"].startswith("rccl gather to rank 0")
+
+
+def test_committed_profile_matches_the_sources_and_the_instruction_budget():
+    """CPU-side guard (no GPU): the rocprofv3 profile bench.py replays its PMC fields from must belong to the committed kernel
+    sources (tools/source_hash.py), and the headline kernel must not have grown — 4.273 G vector instructions per 4096 x 500
+    rotation-steps since round 3 (2086 per wave-step).  A change to the l = 2 instantiation that only moved the launch time
+    by 1 % once slipped through three interleaved A/Bs as noise; its instruction count did not."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import kernel_source_sha16
+    want = kernel_source_sha16(ROOT)
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_cfg2", "counters.json")):
+        d = json.load(open(f))
+        if d.get("_meta", {}).get("kernel_source_sha16") == want:
+            hits.append((f, d))
+    assert hits, f"no profiles/*_cfg2/counters.json for kernel sources {want}: run `bash tools/gpu_session.sh <tag> bench prof2` and commit it"
+    for f, d in hits:
+        v3 = [v for k, v in d.items() if "blind_rotate_kernel_v3<2, 8, true, false, 4>" in k]
+        assert v3, f
+        assert v3[0]["valu_insts_per_launch"] <= 4.28e9, (f, v3[0]["valu_insts_per_launch"])
