@@ -25,18 +25,45 @@
  * copies keys to the device(s) at load time and owns all device memory.  A context made by
  * tfhe_ctx_create is bound to one device; one made by tfhe_ctx_create_multi fans every host-buffer
  * batch call out over its devices on library-owned threads and streams (keys replicated at load,
- * contiguous rotation-balanced shards, results written straight into the caller's buffer).  Calls on
- * one context must not overlap (one caller at a time); distinct contexts are independent.
+ * contiguous rotation-balanced shards, results written straight into the caller's buffer).
  *
- * Parameter sets.  The reference validates nothing (SchemeParameters is a positional struct, tlwe_mask_size a free
- * keyword: api.jl:4-21,30,55).  Single key: tfhe_ctx_create accepts N = 1024 or 2048, tlwe_mask_size k <= 4, any
- * bs_decomp_length l with l * bs_log2_base <= 32, lwe_size <= 1023, any keyswitch base / length with t * gamma <= 31.
- * Tuned kernels: N = 1024 with k = 1 and ANY l (instantiated for the shipped l = 2 and 3; the one- and two-waves-per-rotation
- * kernels also exist with l as a run-time value and serve every other l at the same speed), N = 1024 with k = 2 and l = 2 or 3,
- * N = 2048 with k = 1 and l = 3 (BASELINE config 4b).  Everything else (k >= 3; k = 2 or N = 2048 with another l; N = 2048
- * with k >= 2) runs on blind_rotate_kernel_general — same words, about 3.5 times slower.
- * Multi-key: N = 1024, k = 1 (as the reference, mk_internals.jl:89-91), 2..8 parties, l <= 8.  Outside that
- * (N other than 1024 / 2048, k > 4, multi-key at N = 2048): TFHE_ERR_UNSUPPORTED.
+ * Threading.  The reference is single-threaded and non-re-entrant (global transform plans with shared scratch,
+ * polynomials.jl:80-103).  Here distinct contexts are independent, and calls on ONE context must not overlap: the thread
+ * inside an entry point owns the context until that call returns, and a call made meanwhile from another thread fails with
+ * TFHE_ERR_STATE (tfhe_last_error then tells that thread why) instead of racing on the context's workspaces.  Give every
+ * host thread its own context (keys are per context), or serialise the calls (the Julia binding holds a ReentrantLock).
+ * The asynchronous forms (tfhe_gates_batch_submit, tfhe_gates_batch_dev, tfhe_gates_level) return while the device works;
+ * only their host side is a "call" in this sense.
+ *
+ * Parameter sets.  The reference validates nothing (SchemeParameters is a positional struct, tlwe_mask_size a free keyword:
+ * api.jl:4-21,30,55); decode_message needs 2N to be a power of two (numeric-functions.jl:28-33) and the transform plans an even
+ * length (polynomials.jl:51,69).  tfhe_ctx_create accepts EVERY such set: N any power of two from 2 to 8192, any tlwe_mask_size
+ * k, any bs_decomp_length l with l * bs_log2_base <= 32, any lwe_size, any keyswitch base / length with t * gamma <= 31;
+ * multi-key: any N, any number of parties, any l (k = 1 as the reference hard-wires it, mk_internals.jl:89-91,129-131).
+ * What runs where (every path gives the same words):
+ *   tuned kernels      N = 1024 with k = 1 and ANY l (instantiated for the shipped l = 2 and 3; the one- and two-waves-per-rotation
+ *                      kernels also exist with l as a run-time value and serve every other l at the same speed); N = 1024 with
+ *                      k = 2 and l = 2 or 3; N = 2048 with k = 1 and l = 3 (BASELINE config 4b); multi-key N = 1024: the shipped
+ *                      2- / 4- / 8-party sets
+ *   general kernels    everything else at N = 1024 / 2048 with k <= 4 (blind_rotate_kernel_general, ~3.5 x slower than tuned),
+ *                      multi-key at N = 1024 with up to 8 parties and l <= 8 (mk_blind_rotate_kernel_general)
+ *   any-N kernels      every other set (N other than 1024 / 2048, k > 4, multi-key with N other than 1024, more than 8 parties or
+ *                      l > 8): csrc/kernels_anyn.hpp, one workgroup per rotation, mixed-radix transforms in LDS — correct, untuned
+ *   keyswitch          int8 MFMA kernel for base 4 / t = 8 (k N a multiple of 128), tiled integer kernel for base 4 / t a
+ *                      multiple of 4 (k N <= 2048), gather kernel for every other base, length and size (single- and multi-key)
+ * Refused: N that is no power of two (TFHE_ERR_INVALID_ARG), N > 8192 (TFHE_ERR_UNSUPPORTED: one polynomial's transform no
+ * longer fits a compute unit's 160 KB of LDS — and the Float64 transform, here as in the reference, has no rounding margin
+ * left there), multi-key with tlwe_mask_size != 1 (TFHE_ERR_UNSUPPORTED: as the reference).
+ *
+ * Exactness domain.  Like the reference (polynomials.jl:106-132) the external product goes through a Float64 transform and
+ * ONE rounding per output coefficient (polynomials.jl:115-116: round(Int64, x), low 32 bits).  Every result word is the exact
+ * negacyclic product mod 2^32 as long as (i) the transform's error stays below 1/2 — tfhe_last_rounding_margin measures the
+ * largest distance of a pre-rounding value from an integer; 0.03 - 0.08 at the shipped sets, growing with N, l and
+ * bs_log2_base — and (ii) every pre-rounding value v satisfies |v| < 2^51: the kernels round with the 1.5 * 2^52 trick, exact
+ * there; the reference's round(Int64, .) is defined up to 2^63 but has lost integer precision long before.  With a real key
+ * (uniform words) |v| is around sqrt((k+1) l N) * 2^(bs_log2_base + 29) = 2^44 at the 80-bit set; only a caller-supplied
+ * "key" whose words all share one sign at magnitude 2^31 reaches 2^52 (k = 1, l = 2, beta = 10, N = 1024), where neither
+ * this engine nor the reference computes the exact product (tests/test_any_params.py::test_worst_case_magnitude_key).
  */
 #ifndef TFHE_MI355X_H
 #define TFHE_MI355X_H
@@ -48,7 +75,7 @@
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 5
+#define TFHE_MI355X_ABI_VERSION 6
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -104,7 +131,7 @@ int32_t tfhe_device_count(void);
 
 /* Replaces the implicit construction of TGswParams / KeyswitchParameters / LweParams from
  * SchemeParameters (api.jl:72-82, tgsw.jl:8-21) and validates what the reference does not
- * (api.jl:4-21 has no checks): N power of two, bs_l*bs_log2_base <= 32, ks_t*ks_log2_base <= 31. */
+ * (api.jl:4-21 has no checks): N a power of two (2 .. 8192), bs_l*bs_log2_base <= 32, ks_t*ks_log2_base <= 31. */
 int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx **out_ctx);
 void tfhe_ctx_destroy(tfhe_ctx *ctx);
 
@@ -118,8 +145,13 @@ void tfhe_ctx_destroy(tfhe_ctx *ctx);
  * tfhe_gates_batch_dev needs n_dev == 1 (a device pointer belongs to one device).  tfhe_gates_batch_submit gives every
  * device its shard as a submit of its own, so each keeps two batches in flight.  The wire table (tfhe_wires_*) is
  * replicated on every device; tfhe_gates_level runs a level of fewer than "level_split_min" blind rotations (option,
- * default 4096) on the first device and shards a wider one over all of them, exchanging the written wires through host
- * memory afterwards (no peer access is assumed).  Results are bit-identical to a one-device context. */
+ * default 4096) on the first device and shards a wider one over all of them.  The context tracks which replicas hold each
+ * wire's current value: a device fetches the operand rows it is about to read and does not have — device to device
+ * (hipMemcpyPeerAsync; peer access is switched on at creation wherever hipDeviceCanAccessPeer allows) or through pinned host
+ * memory where it does not (option "level_exchange": 0 = by peer access, 1 / 2 force either path) — on the devices' own streams,
+ * ordered by events: like the one-device call, tfhe_gates_level returns when the level is queued.  Rows nobody else reads
+ * never travel; tfhe_wires_download / _gather bring the first device up to date for what they read.  Results are
+ * bit-identical to a one-device context. */
 int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_ids, int32_t n_dev,
                               tfhe_ctx **out_ctx);
 /* Number of device contexts behind ctx (1 for tfhe_ctx_create). */
@@ -139,7 +171,8 @@ int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
 
 /* BootstrapKey (bootstrap.jl:1-16) from the canonical Int32 form [n][l][k+1][k+1][N].
  * The engine forward-transforms it on the device into its own spectrum-domain layout
- * (the analogue of `forward_transform.(bk)`, bootstrap.jl:12). */
+ * (the analogue of `forward_transform.(bk)`, bootstrap.jl:12).  Any Int32 words are accepted; results are the exact product
+ * within the exactness domain stated at the top of this file (|pre-rounding value| < 2^51: every real key). */
 int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk);
 
 /* BootstrapKey from the reference's stored spectra, complex128 [n][l][k+1][k+1][N/2] as produced by
@@ -222,7 +255,8 @@ int32_t tfhe_wires_download(tfhe_ctx *ctx, int64_t first, int64_t count, int32_t
 int32_t tfhe_wires_gather(tfhe_ctx *ctx, const int32_t *wires, int64_t count, int32_t *host);
 /* wire[out[g]] = gate_<opcode[g]>(ck, wire[a[g]], wire[b[g]], wire[c[g]]) for g < B (host index arrays; b / c
  * may be NULL if no opcode reads them).  A level must not read a wire it writes, nor write a wire twice
- * (TFHE_ERR_INVALID_ARG).  Asynchronous on the context's stream; ordered with later calls. */
+ * (TFHE_ERR_INVALID_ARG).  Asynchronous: returns when the level is queued on the context's stream (multi-device context: on
+ * every participating device's stream, the exchange of operand rows between devices included); ordered with later calls. */
 int32_t tfhe_gates_level(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *a, const int32_t *b,
                          const int32_t *c, const int32_t *out, int64_t B);
 
@@ -237,7 +271,7 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *ctx, const int32_t *in, int32_t *out, int
 
 /* ---- multi-key (mk_gates.jl:7-12, mk_internals.jl:348-411,464-515) --------------------------- */
 
-/* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file); 2 <= P <= 8, P <= the context's `parties`. */
+/* MKBootstrapKey from Int32 [P][n][2*l*P + 2*l][N] (see top of file); 2 <= P <= the context's `parties` (mk_api.jl:94). */
 int32_t tfhe_mk_load_bootstrap_key_i32(tfhe_ctx *ctx, const int32_t *bk, int32_t parties);
 /* The same key in the form the reference stores it (MKBootstrapKey.key[j, i] :: MKTransformedTGswExpSample,
  * mk_internals.jl:274-288,442-461): complex128 [P][n][2*l*P + 2*l][N/2] spectra of polynomials.jl:106-112.  Loading
@@ -252,7 +286,8 @@ int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *ctx, const double *bk_spectra,
 int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *ctx, int32_t parties, const int32_t *pub_b, const int32_t *c0,
                                           const int32_t *c1, const int32_t *d0, const int32_t *d1, const int32_t *f0,
                                           const int32_t *f1, int32_t *expanded_out);
-/* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]. */
+/* P single-key KeyswitchKeys back to back, each [N][t][base-1][n+1]; any base and length (mk_internals.jl:397-411 calls the
+ * single-key keyswitch per party). */
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *ctx, const int32_t *ks, int32_t parties);
 /* out[g] = mk_gate_nand(ck, in0[g], in1[g]); all host int32 [B][P*n+1]. */
 int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *ctx, const int32_t *in0, const int32_t *in1, int32_t *out,
@@ -294,7 +329,10 @@ const char *tfhe_last_kernel_name(const tfhe_ctx *ctx);
 int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
 
 /* Same DIAG run: the shader clock the blind-rotate kernel actually held, in MHz = s_memtime ticks / s_memrealtime
- * ticks x 100 MHz around the kernel body, median over workgroups (what FP64-issue roofline figures are priced at). */
+ * ticks x 100 MHz around the kernel body, median over the workgroups that ran for at least 10 us (what FP64-issue roofline
+ * figures are priced at).  TFHE_ERR_STATE if no workgroup ran that long: the 100 MHz counter is too coarse for a shorter one.
+ * A kernel of a few tens of microseconds right after the device woke up reads the clock of the DVFS ramp, not the sustained
+ * one: price rooflines with the reading of a launch that lasts milliseconds. */
 int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 
 /* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
@@ -306,6 +344,10 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
  * next kernel waiting ~5 us, which a level of a narrow circuit (six short operations around one single-rotation kernel) feels;
  * tfhe_last_timing_ms / tfhe_timing_history_ms then have nothing to report for those calls (TFHE_ERR_STATE). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
+/* The current value of an option (ABI v6): a caller that changes one for a while can put it back.  "br_anyn" (the any-N kernel
+ * where a tuned one exists; like "ks_variant" it decides a key layout and must be chosen before the bootstrapping key is
+ * loaded), "anyn_spec", "level_exchange" are new in v6. */
+int32_t tfhe_get_option(tfhe_ctx *ctx, const char *name, int64_t *value);
 
 #ifdef __cplusplus
 }

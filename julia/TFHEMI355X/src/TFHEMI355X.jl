@@ -64,6 +64,26 @@ function check(ctx::Ptr{Cvoid}, rc::Int32)
     error("tfhe_mi355x error $rc: $msg")
 end
 
+# One caller at a time per context (include/tfhe_mi355x.h, "Threading"): the library answers an overlapping call from another
+# thread with TFHE_ERR_STATE; Julia tasks sharing a key therefore take the context's lock around every call (re-entrant: the
+# scalar gate methods call the batch methods).  The lock also covers tfhe_last_error, whose message belongs to the owner.
+const CTX_LOCKS = Dict{Ptr{Cvoid}, ReentrantLock}()
+const CTX_LOCKS_GUARD = ReentrantLock()
+ctx_lock(ctx::Ptr{Cvoid}) = lock(CTX_LOCKS_GUARD) do
+    get!(() -> ReentrantLock(), CTX_LOCKS, ctx)
+end
+macro locked(ctx, ex)
+    quote
+        local lk = ctx_lock($(esc(ctx)))
+        lock(lk)
+        try
+            $(esc(ex))
+        finally
+            unlock(lk)
+        end
+    end
+end
+
 # tfhe_ctx_create (one device) or tfhe_ctx_create_multi (keys replicated, batch calls fanned out inside the library)
 function create_context(p::SchemeParameters, devices)
     tp = TfheParams(p)
@@ -127,14 +147,14 @@ mutable struct GpuCloudKey
         finalizer(destroy!, gck)
         # no per-phase timing events: nothing in this module reads them, and every record keeps the stream's next kernel
         # waiting ~5 us (six per circuit level; include/tfhe_mi355x.h, tfhe_set_option)
-        check(ctx, ccall((:tfhe_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx, "timing_events", Int64(0)))
+        @locked ctx check(ctx, ccall((:tfhe_set_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx, "timing_events", Int64(0)))
         gck
     end
 end
 
 function destroy!(g)
     if g.ctx != C_NULL
-        ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx)
+        ccall((:tfhe_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), g.ctx)    # (its entry in CTX_LOCKS stays: this may run as a finalizer, which must not take locks; a reused address finds a valid lock)
         g.ctx = C_NULL
     end
     nothing
@@ -145,10 +165,10 @@ function GpuCloudKey(ck::CloudKey; device::Integer=0, devices=nothing, wires::In
     gck = GpuCloudKey(p, devices === nothing ? [device] : devices, wires)
     try
         spectra = flatten_bootstrap_spectra(ck.bootstrap_key, p)
-        GC.@preserve spectra check(gck.ctx, ccall((:tfhe_load_bootstrap_key_c128, LIB), Int32,
+        GC.@preserve spectra @locked gck.ctx check(gck.ctx, ccall((:tfhe_load_bootstrap_key_c128, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Complex{Float64}}), gck.ctx, spectra))
         flat = flatten_keyswitch_key(ck.keyswitch_key, p.lwe_size)
-        GC.@preserve flat check(gck.ctx, ccall((:tfhe_load_keyswitch_key, LIB), Int32,
+        GC.@preserve flat @locked gck.ctx check(gck.ctx, ccall((:tfhe_load_keyswitch_key, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Int32}), gck.ctx, flat))
     catch
         destroy!(gck)
@@ -173,7 +193,7 @@ function GpuCloudKey(rng::AbstractRNG, secret_key::SecretKey; device::Integer=0,
         # operating system's generator whatever `rng` is (Philox then only expands that secret), discarded here
         seed = vcat(rand(rng, UInt32, 2), noise_seed === nothing ? rand(RandomDevice(), UInt32, 4) : UInt32.(noise_seed))
         length(seed) == 6 || error("GpuCloudKey: noise_seed must be four 32-bit words")
-        GC.@preserve lwe_bits tlwe_bits seed check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
+        GC.@preserve lwe_bits tlwe_bits seed @locked gck.ctx check(gck.ctx, ccall((:tfhe_keygen_cloud_key, LIB), Int32,
             (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Float64, Float64, Ptr{UInt32}, Ptr{Int32}, Ptr{Int32}),
             gck.ctx, lwe_bits, tlwe_bits, p.bs_noise_stddev, p.ks_noise_stddev, seed, C_NULL, C_NULL))
     catch
@@ -225,7 +245,7 @@ Base.length(d::GpuLweArray) = length(d.rows)
 
 function alloc_rows!(g::GpuCloudKey, count::Int)
     if !g.wire_ready                                                       # first use: allocate the table
-        check(g.ctx, ccall((:tfhe_wires_alloc, LIB), Int32, (Ptr{Cvoid}, Int64), g.ctx, g.wire_capacity))
+        @locked g.ctx check(g.ctx, ccall((:tfhe_wires_alloc, LIB), Int32, (Ptr{Cvoid}, Int64), g.ctx, g.wire_capacity))
         g.wire_ready = true
     end
     returned = g.wire_returned
@@ -260,12 +280,12 @@ function upload(g::GpuCloudKey, xs::AbstractVector{LweSample})
     first_fresh = isempty(rows) ? 0 : rows[1]
     contiguous = rows == collect(Int32, first_fresh:(first_fresh + length(rows) - 1))
     if contiguous
-        GC.@preserve flat check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
+        GC.@preserve flat @locked g.ctx check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
             (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}), g.ctx, first_fresh, length(rows), flat))
     else                                                                 # recycled rows: one copy per row
         n1 = size(flat, 1)
         for (i, r) in enumerate(rows)
-            GC.@preserve flat check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
+            GC.@preserve flat @locked g.ctx check(g.ctx, ccall((:tfhe_wires_upload, LIB), Int32,
                 (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}), g.ctx, r, 1, pointer(flat, (i - 1) * n1 + 1)))
         end
     end
@@ -278,7 +298,7 @@ end
 function download(d::GpuLweArray)
     g = d.key
     out = Array{Int32}(undef, g.params.lwe_size + 1, length(d))
-    GC.@preserve out check(g.ctx, ccall((:tfhe_wires_gather, LIB), Int32,
+    GC.@preserve out @locked g.ctx check(g.ctx, ccall((:tfhe_wires_gather, LIB), Int32,
         (Ptr{Cvoid}, Ptr{Int32}, Int64, Ptr{Int32}), g.ctx, d.rows, length(d), out))
     unflatten(out, LweParams(g.params.lwe_size))
 end
@@ -319,7 +339,7 @@ function gates_batch(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=nothing, z
     fz = zs === nothing ? nothing : flatten(zs)
     out = Array{Int32}(undef, gck.params.lwe_size + 1, B)
     ptr(a) = a === nothing ? Ptr{Int32}(C_NULL) : pointer(a)
-    GC.@preserve fx fy fz out opcodes check(gck.ctx, ccall((:tfhe_gates_batch, LIB), Int32,
+    GC.@preserve fx fy fz out opcodes @locked gck.ctx check(gck.ctx, ccall((:tfhe_gates_batch, LIB), Int32,
         (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64),
         gck.ctx, opcodes, ptr(fx), ptr(fy), ptr(fz), out, B))
     unflatten(out, params)
@@ -360,12 +380,12 @@ function gates_batch_async(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=noth
     ptr(a) = a === nothing ? Ptr{Int32}(C_NULL) : pointer(a)
     ticket = Ref{Int32}(-1)
     bufs = Array{Int32}[b for b in (fx, fy, fz, out) if b !== nothing]
-    rc = ccall((:tfhe_gates_batch_submit, LIB), Int32,
+    rc = @locked gck.ctx ccall((:tfhe_gates_batch_submit, LIB), Int32,
         (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64, Ptr{Int32}),
         gck.ctx, opcodes, ptr(fx), ptr(fy), ptr(fz), out, B, ticket)
     if rc != 0
         foreach(release_pinned, bufs)
-        check(gck.ctx, rc)
+        @locked gck.ctx check(gck.ctx, rc)
     end
     t = PendingGates(gck, ticket[], bufs, out, false)
     # a PendingGates that is dropped (or whose fetch is never reached) must not leak its page-locked buffers: wait for the
@@ -387,7 +407,7 @@ end
 
 function Base.fetch(t::PendingGates)
     t.done && error("PendingGates: already fetched")
-    rc = ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)
+    rc = @locked t.key.ctx ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)
     if rc != 0
         # a failed wait says nothing about the copies still in flight: wait on both streams before the buffers go back
         for other in Int32(0):Int32(1)
@@ -417,7 +437,7 @@ function gates_on_device(g::GpuCloudKey, op::UInt8, operands)
     out = alloc_rows!(g, B)
     opcodes = fill(op, B)
     ptr(a) = isempty(a) ? Ptr{Int32}(C_NULL) : pointer(a)
-    GC.@preserve opcodes ia ib ic out devs check(g.ctx, ccall((:tfhe_gates_level, LIB), Int32,
+    GC.@preserve opcodes ia ib ic out devs @locked g.ctx check(g.ctx, ccall((:tfhe_gates_level, LIB), Int32,
         (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64),
         g.ctx, opcodes, ptr(ia), ptr(ib), ptr(ic), out, B))
     GpuLweArray(g, out)
@@ -504,11 +524,11 @@ mutable struct GpuMKCloudKey
         finalizer(destroy!, mck)
         try
             spectra = flatten_mk_spectra(ck.bootstrap_key, p, P)
-            GC.@preserve spectra check(ctx, ccall((:tfhe_mk_load_bootstrap_key_c128, LIB), Int32,
+            GC.@preserve spectra @locked ctx check(ctx, ccall((:tfhe_mk_load_bootstrap_key_c128, LIB), Int32,
                 (Ptr{Cvoid}, Ptr{Complex{Float64}}, Int32), ctx, spectra, Int32(P)))
             # P single-key keyswitch keys back to back (src/mk_api.jl:97-98)
             flat = cat([flatten_keyswitch_key(ks, p.lwe_size) for ks in ck.keyswitch_key]...; dims=5)
-            GC.@preserve flat check(ctx, ccall((:tfhe_mk_load_keyswitch_key, LIB), Int32,
+            GC.@preserve flat @locked ctx check(ctx, ccall((:tfhe_mk_load_keyswitch_key, LIB), Int32,
                 (Ptr{Cvoid}, Ptr{Int32}, Int32), ctx, flat, Int32(P)))
         catch
             destroy!(mck)
@@ -538,7 +558,7 @@ function mk_nand_batch(mck::GpuMKCloudKey, xs::MKVec, ys::MKVec)
     n, P, B = mck.params.lwe_size, mck.parties, length(xs)
     fx, fy = flatten(xs), flatten(ys)
     out = Array{Int32}(undef, n * P + 1, B)
-    GC.@preserve fx fy out check(mck.ctx, ccall((:tfhe_mk_gate_nand_batch, LIB), Int32,
+    GC.@preserve fx fy out @locked mck.ctx check(mck.ctx, ccall((:tfhe_mk_gate_nand_batch, LIB), Int32,
         (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int64), mck.ctx, fx, fy, out, B))
     params = LweParams(n)
     # current_variance: 0.0 as the reference's own TODO leaves it (src/mk_internals.jl:94)

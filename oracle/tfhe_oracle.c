@@ -28,11 +28,11 @@
 #include <omp.h>
 #endif
 
-#define ORC_MAX_N 4096
+#define ORC_MAX_N 8192
 #define ORC_MAX_L 32        /* single key: any l with l * beta <= 32 */
-#define ORC_MAX_L_MK 8      /* multi-key (thread-local digit buffers are sized by it) */
-#define ORC_MAX_K 4
-#define ORC_MAX_PARTIES 8
+#define ORC_MAX_L_MK 32     /* multi-key: the same bound (the digit buffers are per-thread heap blocks sized by need) */
+#define ORC_MAX_K 8
+#define ORC_MAX_PARTIES 64
 
 typedef struct {
     int32_t n;        /* lwe_size                 api.jl:6  */
@@ -145,14 +145,14 @@ typedef struct {
     int *rev;
 } orc_plan;
 
-static orc_plan g_plans[4];
+static orc_plan g_plans[16];      /* one per polynomial length seen by this process */
 static int g_nplans = 0;
 
 /* Must be called (single-threaded) before any transform of length N. */
 int orc_init(int32_t N)
 {
     for (int i = 0; i < g_nplans; i++) if (g_plans[i].N == N) return 0;
-    if (g_nplans >= 4 || N > ORC_MAX_N || N < 4 || (N & (N - 1))) return -1;
+    if (g_nplans >= 16 || N > ORC_MAX_N || N < 4 || (N & (N - 1))) return -1;
     orc_plan *p = &g_plans[g_nplans];
     const int M = N / 2;
     p->N = N; p->M = M;
@@ -559,6 +559,19 @@ int orc_keyswitch_batch(const orc_params *P, const int32_t *ks, const int32_t *i
  * ===========================================================================================*/
 static inline size_t mk_polys_per_key(int l, int Pn) { return (size_t)2 * l * Pn + 2 * l; }
 
+/* per-thread scratch blocks of the multi-key functions, grown to what (parties, l, N) need and kept for the thread's life */
+static void *mk_ws(int slot, size_t bytes)
+{
+    static _Thread_local void *blk[6];
+    static _Thread_local size_t cap[6];
+    if (bytes > cap[slot]) {
+        free(blk[slot]);
+        blk[slot] = malloc(bytes);
+        cap[slot] = blk[slot] ? bytes : 0;
+    }
+    return blk[slot];
+}
+
 /* mk_internals.jl:348-391 — result added into acc (mk_mux_rotate :469) */
 static void mk_extern_mul_add(const orc_params *P, int Pn, int party, const int32_t *temp /*[(Pn+1)][N]*/,
                               const double *kre, const double *kim, const int32_t *ki32, int mode,
@@ -566,12 +579,12 @@ static void mk_extern_mul_add(const orc_params *P, int Pn, int party, const int3
 {
     const int N = P->N, M = N / 2, l = P->l;
     /* decompose all Pn masks and b: dec[(i)][p][N], i = 0..Pn (Pn == b)      :355-356 */
-    static _Thread_local int32_t dec[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * ORC_MAX_N];
+    int32_t *dec = mk_ws(0, sizeof(int32_t) * (size_t)(Pn + 1) * l * N);
     for (int i = 0; i <= Pn; i++) orc_decompose(temp + (size_t)i * N, N, l, P->log2Bg, dec + (size_t)i * l * N);
     const size_t X0 = 0, Y0 = (size_t)l * Pn, C0 = (size_t)2 * l * Pn, C1 = C0 + l;
 
     if (mode == 1) {
-        static _Thread_local uint32_t out[(ORC_MAX_PARTIES + 1) * ORC_MAX_N];
+        uint32_t *out = mk_ws(1, sizeof(uint32_t) * (size_t)(Pn + 1) * N);
         memset(out, 0, sizeof(uint32_t) * (size_t)(Pn + 1) * N);
         for (int i = 0; i < Pn; i++) {
             for (int p = 0; p < l; p++) {
@@ -594,8 +607,8 @@ static void mk_extern_mul_add(const orc_params *P, int Pn, int party, const int3
     }
     /* mode 0: the reference inverse-transforms every product separately and sums in Int32
      * (:359-366 explains why); restated literally. */
-    static _Thread_local double dre[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * (ORC_MAX_N / 2)];
-    static _Thread_local double dim[(ORC_MAX_PARTIES + 1) * ORC_MAX_L_MK * (ORC_MAX_N / 2)];
+    double *dre = mk_ws(2, sizeof(double) * (size_t)(Pn + 1) * l * M);
+    double *dim = mk_ws(3, sizeof(double) * (size_t)(Pn + 1) * l * M);
     for (int i = 0; i <= Pn; i++)
         for (int p = 0; p < l; p++)                                                         /* :368-369 */
             orc_forward_transform(dec + ((size_t)i * l + p) * N, N, dre + ((size_t)i * l + p) * M, dim + ((size_t)i * l + p) * M);
@@ -641,8 +654,9 @@ int orc_mk_bootstrap_wo_keyswitch(const orc_params *P, int32_t Pn, const double 
     if (Pn > ORC_MAX_PARTIES || N > ORC_MAX_N || l > ORC_MAX_L_MK) return -1;
     if (mode == 0 && !get_plan(N)) return -1;
     const int log2_2N = ilog2(2 * N);
-    static _Thread_local int32_t acc[(ORC_MAX_PARTIES + 1) * ORC_MAX_N], temp[(ORC_MAX_PARTIES + 1) * ORC_MAX_N];
+    int32_t *acc = mk_ws(4, sizeof(int32_t) * (size_t)(Pn + 1) * N), *temp = mk_ws(5, sizeof(int32_t) * (size_t)(Pn + 1) * N);
     int32_t tv[ORC_MAX_N];
+    if (!acc || !temp) return -1;
     if (margin) *margin = 0;
     const int32_t barb = orc_decode_message(x[(size_t)Pn * n], log2_2N);      /* :502 */
     for (int j = 0; j < N; j++) tv[j] = mu;                                    /* :506 */

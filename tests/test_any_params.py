@@ -1,0 +1,383 @@
+"""Never refuse an input the reference accepts (round-4 verdict, next #1): SchemeParameters is an unvalidated positional struct
+(api.jl:4-21), decode_message / the transform plans only need 2N to be a power of two (numeric-functions.jl:31-34,
+polynomials.jl:44-58), keyswitch.jl:45-80 takes any base and length.  Parameter sets outside what the tuned kernels were built
+for — N other than 1024 / 2048, k > 4, lwe_size + 1 > 1024, a keyswitch base other than 4 — through the C ABI against the oracle
+word for word, their DIAG instantiation with the rounding margin asserted, and gates decrypted."""
+import itertools
+
+import numpy as np
+import pytest
+
+MU = 2**29
+
+
+def _setup(tfhe, orc, n, N, k, l, beta, t=8, gamma=2, seed=0, bs_noise=9e-9):
+    from conftest import KeySet
+    p = tfhe.SchemeParameters(n, 1 / 2**15, N, k, l, beta, bs_noise, t, gamma, 1 / 2**15, 1)
+    return KeySet(tfhe, orc, p, seed=7000 + 13 * N + 100 * k + 10 * l + n + seed)
+
+
+def _words(rng, rows, width):
+    x = rng.integers(-2**31, 2**31, size=(rows, width), dtype=np.int64).astype(np.int32)
+    x[0, :] = 0
+    x[1, :min(7, width)] = [2**31 - 1, -2**31, 2**20, 2**20 - 1, -2**20, -2**20 - 1, 1][:min(7, width)]
+    return x
+
+
+def _check_rotation(eng, K, x, expect_kernel, what):
+    want = K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == expect_kernel, (what, eng.last_kernel_name())
+    assert np.array_equal(got, want), what
+    eng.set_option("measure_margin", 1)
+    try:
+        again = eng.bootstrap(MU, x, with_keyswitch=False)
+        assert eng.last_kernel_name() == expect_kernel
+        margin = eng.last_rounding_margin()
+    finally:
+        eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, want), what + " (DIAG instantiation)"
+    assert 0.0 <= margin < 0.25, (what, margin)
+    return margin
+
+
+def _check_gates(tfhe, eng, K, what):
+    combos = list(itertools.product((False, True), repeat=3))
+    ins = [tfhe.encrypt(K.rng, K.sk, [c[i] for c in combos]).data for i in range(3)]
+    for name, ref in (("NAND", lambda a, b, c: not (a and b)), ("XOR", lambda a, b, c: a != b), ("MUX", lambda a, b, c: b if a else c)):
+        ops = np.full(8, tfhe.OPCODES[name], np.uint8)
+        got = eng.gates(ops, *ins)
+        assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=8)), (what, name)
+        if K.params.tlwe_polynomial_degree >= 64:       # (below that the modulus switch to 2N levels is too coarse for the message to survive)
+            assert list(tfhe.decrypt(K.sk, got)) == [bool(ref(*c)) for c in combos], (what, name)
+
+
+ANY_N = [  # what, n, N, k, l, beta
+    ("N = 512 (half of the shipped degree)", 6, 512, 1, 2, 10),
+    ("N = 4096", 4, 4096, 1, 3, 7),
+    ("N = 256, k = 2", 6, 256, 2, 3, 6),
+    ("N = 64", 5, 64, 1, 4, 4),
+    ("N = 8, k = 3", 5, 8, 3, 2, 8),
+    ("N = 8192", 2, 8192, 1, 2, 7),
+    ("N = 1024, k = 5", 4, 1024, 5, 2, 8),
+    ("N = 2048, k = 6", 3, 2048, 6, 2, 8),
+    ("N = 128, l = 16 / beta = 2", 4, 128, 1, 16, 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what,n,N,k,l,beta", ANY_N, ids=[a[0] for a in ANY_N])
+def test_any_polynomial_degree_and_mask_size(tfhe, orc, what, n, N, k, l, beta):
+    """anyn::blind_rotate_kernel: every power-of-two N from 8 to 8192, k beyond 4: blind rotation on arbitrary words + its DIAG
+    instantiation against the oracle, then whole gates (prologue, keyswitch from kN words) decrypted and against the oracle."""
+    K = _setup(tfhe, orc, n, N, k, l, beta)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(N + k + l), 5, n + 1)
+    # the k + 1 spectrum accumulators of a step live in LDS when buffer + accumulators + digit words fit a CU's 160 KB
+    # (anyn::lds_bytes), in global memory otherwise; option anyn_spec forces the second placement on every set
+    Mp = N // 2 + N // 16
+    fits = (2 + k) * Mp * 16 + 4 * N + 16 <= 160 * 1024
+    margin = _check_rotation(eng, K, x, f"blind_rotate_kernel_anyn(N={N},k={k},l={l}" + (")" if fits else ",spec=global)"), what)
+    print(f"  rounding margin, {what}: {margin:.4f}")
+    eng.set_option("anyn_spec", 1)
+    _check_rotation(eng, K, x, f"blind_rotate_kernel_anyn(N={N},k={k},l={l},spec=global)", what + ", spectrum accumulators in global memory")
+    eng.set_option("anyn_spec", -1)
+    _check_gates(tfhe, eng, K, what)
+    K.ck.close()
+
+
+@pytest.mark.gpu
+def test_n4096_margin_at_the_80bit_decomposition(tfhe, orc):
+    """The rounding margin tightens with N: at N = 4096 with tfhe_parameters_80's decomposition (l = 2, beta = 10: digits up to
+    2^9, polynomials.jl:115-116 rounds values around 2^45) it is measured here on 64 rotations of arbitrary words and must stay
+    below 0.25 — the same Float64 transform the reference runs has the same margin."""
+    K = _setup(tfhe, orc, 8, 4096, 1, 2, 10)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(4096), 64, 9)
+    margin = _check_rotation(eng, K, x, "blind_rotate_kernel_anyn(N=4096,k=1,l=2)", "N = 4096, l = 2, beta = 10")
+    print(f"  rounding margin at N = 4096, l = 2, beta = 10: {margin:.4f}")
+    K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,k,l,beta", [(1024, 1, 2, 10), (1024, 1, 3, 7), (1024, 2, 2, 10), (2048, 1, 3, 7)])
+def test_anyn_kernel_equals_the_tuned_ones(tfhe, orc, N, k, l, beta):
+    """Option br_anyn (chosen before the key is loaded: the any-N kernels keep the key in their own spectrum order): the any-N
+    kernel on the shapes that have a tuned kernel gives the tuned kernel's words, and the oracle's."""
+    K = _setup(tfhe, orc, 6, N, k, l, beta, seed=1)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(5), 5, 7)
+    tuned = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert "anyn" not in eng.last_kernel_name()
+    with pytest.raises(tfhe.EngineError):
+        eng.set_option("br_anyn", 1)                     # the key is already loaded in the tuned kernels' order
+    e2 = tfhe.Engine(K.params, 0)
+    e2.set_option("br_anyn", 1)
+    e2.load_bootstrap_key(K.ck.bootstrap_key)
+    e2.load_keyswitch_key(K.ck.keyswitch_key)
+    _check_rotation(e2, K, x, f"blind_rotate_kernel_anyn(N={N},k={k},l={l})", "br_anyn")
+    assert np.array_equal(e2.bootstrap(MU, x, with_keyswitch=False), tuned)
+    e2.close()
+    K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [512, 4096, 32])
+def test_anyn_spectra_key_load_equals_int32_load(tfhe, orc, N):
+    """The reference's stored form of the key (complex128 spectra in natural frequency order, bootstrap.jl:12-14) loads into the
+    any-N kernels' digit-reversed order by a permutation: same result words as the Int32 load."""
+    K = _setup(tfhe, orc, 4, N, 1, 2, 8, seed=2)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(N), 4, 5)
+    want = eng.bootstrap(MU, x, with_keyswitch=False)
+    e2 = tfhe.Engine(K.params, 0)
+    e2.load_bootstrap_key_spectra(K.oracle.bk_spectra())
+    assert np.array_equal(e2.bootstrap(MU, x, with_keyswitch=False), want)
+    assert np.array_equal(want, K.oracle.bootstrap(MU, x, with_keyswitch=False))
+    e2.close()
+    K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks_variant", [4, 3, 1])
+def test_lwe_size_1500(tfhe, orc, ks_variant):
+    """lwe_size + 1 > 1024 (refused until round 4): tfhe_parameters_80's TLWE side with lwe_size = 1500 — 1500 CMUX steps, samples
+    of 1501 words through the prologue, the three keyswitch kernel families and the trivial gates — against the oracle, decrypted."""
+    from conftest import KeySet
+    p = tfhe.SchemeParameters(1500, 1 / 2**17, 1024, 1, 2, 10, 9e-9, 8, 2, 1 / 2**17, 1)
+    K = KeySet(tfhe, orc, p, seed=1500)
+    eng = tfhe.Engine(p, 0)
+    eng.set_option("ks_variant", ks_variant)
+    eng.load_bootstrap_key(K.ck.bootstrap_key)
+    eng.load_keyswitch_key(K.ck.keyswitch_key)
+    rng = np.random.default_rng(15)
+    B = 12
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
+    names = ["NAND", "MUX", "XOR", "NOT", "CONST1", "AND", "OR", "COPY", "XNOR", "MUX", "ANDNY", "ORYN"]
+    ops = np.array([tfhe.OPCODES[nm] for nm in names], np.uint8)
+    got = eng.gates(ops, *ins)
+    assert np.array_equal(got, K.oracle.gates(ops, *ins, nthreads=8))
+    a, b, c = bits
+    want_bits = {"NAND": ~(a & b), "MUX": np.where(a, b, c), "XOR": a ^ b, "NOT": ~a, "CONST1": np.ones(B, bool), "AND": a & b, "OR": a | b,
+                 "COPY": a, "XNOR": ~(a ^ b), "ANDNY": ~a & b, "ORYN": a | ~b}
+    dec = tfhe.decrypt(K.sk, got)
+    for g, nm in enumerate(names):
+        assert dec[g] == want_bits[nm][g], nm
+    # arbitrary words through the keyswitch alone
+    u = _words(rng, 5, 1025)
+    assert np.array_equal(eng.keyswitch(u), K.oracle.keyswitch(u))
+    eng.close()
+    K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,N,t,gamma", [(700, 1024, 5, 3), (2047, 512, 3, 5), (40, 1024, 15, 2), (33, 64, 4, 1)])
+def test_keyswitch_any_base_any_size(tfhe, orc, n, N, t, gamma):
+    """keyswitch.jl:45-80 for a base other than 4 / a length other than 8 / lwe_size up to 2047: the gather kernel, arbitrary
+    words against the oracle (and a gate through it)."""
+    K = _setup(tfhe, orc, n, N, 1, 2, 8, t=t, gamma=gamma)
+    eng = K.ck.engine(0)
+    u = _words(np.random.default_rng(n), 6, N + 1)
+    assert np.array_equal(eng.keyswitch(u), K.oracle.keyswitch(u))
+    if n <= 64:
+        _check_gates(tfhe, eng, K, f"keyswitch t = {t}, base {1 << gamma}")
+    K.ck.close()
+
+
+# ---- multi-key ------------------------------------------------------------------------------------------------------
+def _mk(tfhe, orc, parties, N, l, beta, n, t=8, gamma=2, max_parties=None, seed=0, expand="host"):
+    p = tfhe.SchemeParameters(n, 0.012467, N, 1, l, beta, 3.29e-10, t, gamma, 2.44e-5, max_parties or parties)
+    rng = np.random.default_rng(9000 + 17 * parties + N + l + seed)
+    sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
+    shared = tfhe.SharedKey(rng, p)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks], expand=expand)
+    return p, rng, sks, ck
+
+
+def _mk_oracle(orc, p, parties, ck):
+    o = orc.Oracle(p.lwe_size, p.tlwe_polynomial_degree, 1, p.bs_decomp_length, p.bs_log2_base, p.ks_decomp_length, p.ks_log2_base, parties=parties)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    return o
+
+
+def _mk_check(tfhe, eng, o, rng, sks, n, expect_kernel, decrypts=True):
+    P = len(sks)
+    w = P * n + 1
+    x, y = _words(rng, 4, w), _words(rng, 4, w)[::-1].copy()
+    x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
+    y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    want = o.mk_gate_nand(x, y, nthreads=8)
+    got = eng.mk_gate_nand(x, y)
+    assert eng.last_kernel_name() == expect_kernel, eng.last_kernel_name()
+    assert np.array_equal(got, want)
+    if decrypts:
+        assert list(tfhe.mk_decrypt(sks, got[2:4])) == [False, True]
+    eng.set_option("measure_margin", 1)
+    try:
+        again = eng.mk_gate_nand(x, y)
+        margin = eng.last_rounding_margin()
+    finally:
+        eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, want)
+    assert 0.0 <= margin < 0.25, margin
+    return margin
+
+
+MK_ANY = [  # what, parties, N, l, beta, n
+    ("2 parties, N = 512", 2, 512, 4, 7, 6),
+    ("3 parties, N = 2048", 3, 2048, 3, 7, 3),
+    ("9 parties (more than the shipped 8)", 9, 1024, 4, 6, 2),
+    ("2 parties, l = 10 / beta = 3", 2, 1024, 10, 3, 4),
+    ("2 parties, N = 64", 2, 64, 4, 5, 5),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what,parties,N,l,beta,n", MK_ANY, ids=[m[0] for m in MK_ANY])
+def test_mk_any_degree_any_party_count(tfhe, orc, what, parties, N, l, beta, n):
+    """anyn::mk_blind_rotate_kernel: multi-key sets the tuned kernels do not cover (mk_internals.jl takes any N, any number of
+    parties up to max_parties, any decomposition): mk_gate_nand on arbitrary words and on encryptions against the oracle, DIAG
+    margin; the device's RGSW.Expand (anyn::mk_expand_kernel) gives the host expansion's words."""
+    p, rng, sks, ck = _mk(tfhe, orc, parties, N, l, beta, n)
+    o = _mk_oracle(orc, p, parties, ck)
+    eng = ck.engine(0)
+    name = f"mk_blind_rotate_kernel_anyn(N={N},P={parties},l={l})"
+    margin = _mk_check(tfhe, eng, o, rng, sks, n, name, decrypts=N >= 512)
+    print(f"  rounding margin, multi-key {what}: {margin:.4f}")
+    eng.set_option("anyn_spec", 1)
+    _mk_check(tfhe, eng, o, rng, sks, n, name[:-1] + ",spec=global)", decrypts=N >= 512)
+    # RGSW.Expand on the device == on the host
+    e2 = tfhe.Engine(p, 0)
+    arrays = ck._part_arrays()
+    expanded = e2.mk_expand_load_bootstrap_key(parties, *arrays, want_expanded=True)
+    assert np.array_equal(expanded.reshape(ck.bootstrap_key.shape), ck.bootstrap_key)
+    e2.mk_load_keyswitch_key(ck.keyswitch_key, parties)
+    _mk_check(tfhe, e2, o, rng, sks, n, name, decrypts=N >= 512)
+    e2.close()
+    ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t,gamma,n", [(5, 3, 12), (3, 5, 300), (12, 2, 20)])
+def test_mk_keyswitch_any_base(tfhe, orc, t, gamma, n):
+    """mk_keyswitch (mk_internals.jl:397-411) with a base other than 4 / a length that is no multiple of 4 (refused until round 4):
+    mktfhe_parameters_2party's bootstrap side (the tuned two-wave kernel), per-party gather keyswitch."""
+    p, rng, sks, ck = _mk(tfhe, orc, 2, 1024, 4, 7, n, t=t, gamma=gamma, seed=t)
+    o = _mk_oracle(orc, p, 2, ck)
+    eng = ck.engine(0)
+    _mk_check(tfhe, eng, o, rng, sks, n, "mk_blind_rotate_kernel_w2<4>")
+    ck.close()
+
+
+# ---- the context's guard, the exactness domain, the timing ring ----------------------------------------------------------
+@pytest.mark.gpu
+def test_overlapping_calls_on_one_context_are_refused_not_raced(tfhe, orc, keys80):
+    """include/tfhe_mi355x.h, "Threading": two host threads hammer ONE context (ctypes releases the GIL inside a call, so the calls
+    really overlap).  Every call either succeeds with exactly the words of an undisturbed call, or fails with TFHE_ERR_STATE and a
+    message that says why — nothing else ever comes out (before round 5 the two calls raced on the shared workspaces)."""
+    import threading
+    K = keys80
+    eng = tfhe.Engine(K.params, 0)
+    eng.load_bootstrap_key(K.ck.bootstrap_key)
+    eng.load_keyswitch_key(K.ck.keyswitch_key)
+    rng = np.random.default_rng(77)
+    B = 96
+    ops = np.array([tfhe.OPCODES[nm] for nm in ("NAND", "XOR", "MUX", "AND")], np.uint8)[rng.integers(0, 4, B)]
+    sets = []
+    for _ in range(2):
+        ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
+        sets.append((ins, eng.gates(ops, *ins)))
+    assert np.array_equal(sets[0][1][:8], K.oracle.gates(ops[:8], *[a[:8] for a in sets[0][0]], nthreads=8))
+    stats = [dict(ok=0, busy=0, other=[]) for _ in range(2)]
+    stop = threading.Event()
+
+    def worker(i):
+        ins, want = sets[i]
+        while not stop.is_set():
+            try:
+                got = eng.gates(ops, *ins)
+            except tfhe.EngineError as e:
+                if e.code == 5 and "must not overlap" in str(e):
+                    stats[i]["busy"] += 1
+                else:
+                    stats[i]["other"].append(str(e))
+                continue
+            if np.array_equal(got, want):
+                stats[i]["ok"] += 1
+            else:
+                stats[i]["other"].append("wrong words")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    import time
+    time.sleep(2.0)
+    stop.set()
+    for t in threads:
+        t.join()
+    print("  two threads on one context:", stats)
+    assert not stats[0]["other"] and not stats[1]["other"], stats
+    assert stats[0]["ok"] + stats[1]["ok"] > 0 and stats[0]["busy"] + stats[1]["busy"] > 0, stats
+    assert np.array_equal(eng.gates(ops, *sets[0][0]), sets[0][1])       # the context is as usable as before
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_worst_case_magnitude_key(tfhe, orc):
+    """The exactness domain stated in include/tfhe_mi355x.h.  (i) A "key" of uniformly random full-range words with the extremes
+    2^31 - 1 and -2^31 planted in it (what any real key looks like to the kernels): the blind rotation equals the oracle's EXACT
+    integer back-end word for word.  (ii) A "key" whose every word is -2^31 at the 80-bit decomposition: the pre-rounding values are
+    multiples of 2^31 of magnitude up to 2^52, beyond the |v| < 2^51 domain of round_to_torus32 and at the edge of what a Float64
+    holds as an integer — documented here: the engine still returns, the reference-style FFT back-end of the oracle is
+    outside ITS exactness there too (its margin against the exact product is recorded), and nothing is asserted about the words."""
+    n, N, l, beta = 4, 1024, 2, 10
+    p = tfhe.SchemeParameters(n, 0.0, N, 1, l, beta, 0.0, 8, 2, 0.0, 1)
+    rng = np.random.default_rng(2 ** 31 - 1)
+    x = _words(rng, 6, n + 1)
+    bk = rng.integers(-2**31, 2**31, size=(n, l, 2, 2, N), dtype=np.int64).astype(np.int32)
+    bk[:, :, :, :, ::97] = 2**31 - 1
+    bk[:, :, :, :, 5::89] = -2**31
+    o = orc.Oracle(n, N, 1, l, beta, 8, 2)
+    o.load_bootstrap_key(bk)
+    eng = tfhe.Engine(p, 0)
+    eng.load_bootstrap_key(bk)
+    want = o.bootstrap(MU, x, with_keyswitch=False, mode=orc.MODE_EXACT)
+    assert np.array_equal(eng.bootstrap(MU, x, with_keyswitch=False), want)
+    eng.set_option("measure_margin", 1)
+    assert np.array_equal(eng.bootstrap(MU, x, with_keyswitch=False), want)
+    margin = eng.last_rounding_margin()
+    eng.set_option("measure_margin", 0)
+    assert margin < 0.25, margin
+    # (ii) every word -2^31
+    bad = np.full((n, l, 2, 2, N), -2**31, np.int64).astype(np.int32)
+    o.load_bootstrap_key(bad)
+    eng.load_bootstrap_key(bad)
+    exact = o.bootstrap(MU, x, with_keyswitch=False, mode=orc.MODE_EXACT)
+    ref_fft = o.bootstrap(MU, x, with_keyswitch=False, mode=orc.MODE_FFT)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert got.shape == exact.shape
+    print(f"  all-(-2^31) key: engine differs from the exact product in {int((got != exact).sum())} of {exact.size} words, "
+          f"the reference-style FFT of the oracle in {int((ref_fft != exact).sum())}")
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_timing_history_never_reports_the_slot_being_recorded(tfhe, keys80):
+    """tfhe_timing_history_ms after more calls than the ring holds: 32 entries, each a finished call's positive duration (round-4
+    advice: the slot the next call records into must not be part of the history)."""
+    K = keys80
+    eng = tfhe.Engine(K.params, 0)
+    eng.load_bootstrap_key(K.ck.bootstrap_key)
+    eng.load_keyswitch_key(K.ck.keyswitch_key)
+    x = tfhe.encrypt(K.rng, K.sk, [True, False]).data
+    ops = np.zeros(2, np.uint8)
+    for i in range(40):
+        eng.gates(ops, x, x)
+        if i == 20:
+            with pytest.raises(tfhe.EngineError):
+                eng.gates(np.array([99, 0], np.uint8), x, x)      # a failing call in between records nothing
+    h = eng.timing_history_ms(2)
+    assert len(h) == 32 and all(0.0 < v < 1000.0 for v in h), h
+    eng.close()

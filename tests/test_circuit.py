@@ -165,8 +165,10 @@ def test_log_depth_minimum_circuit_on_device(tfhe, orc, keys80):
 def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
     """A multi-device context ({0, 0} on the one-GPU box: two device contexts, two replicas of the wire table) runs narrow
     levels on its first device and shards wide ones (option level_split_min, lowered here so that the 17- and 16-gate levels
-    of the tutorial circuit split), exchanging the written wires through host memory: same words as one device, for the
-    reference's circuit (examples/tutorial.jl:42-62) and for the log-depth variant whose wide levels feed narrow ones."""
+    of the tutorial circuit split).  A device fetches the operand rows whose current value another device holds right before it
+    reads them — device to device (hipMemcpyPeerAsync; option level_exchange 1) or through pinned host memory (2), both
+    forced here, 0 = by peer access — and nothing else travels: same words as one device, every intermediate wire included,
+    for the reference's circuit (examples/tutorial.jl:42-62) and for the log-depth variant whose wide levels feed narrow ones."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     from tutorial import encrypted_minimum_circuit
@@ -176,13 +178,19 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
     multi = K.ck.engine([0, 0])
     for circ in (tutorial_min_circuit(tfhe, 16), encrypted_minimum_circuit(16, log_depth=True)):
         want = circ.run(K.ck, enc).data
-        for split in (4096, 8, 2):            # never split at these sizes / only the 16-gate levels / everything but single gates
-            multi.set_option("level_split_min", split)
-            got = circ.run(K.ck, enc, device=[0, 0]).data
-            assert np.array_equal(got, want), split
-            # the last level of both circuits is 16 parallel MUXes = 32 rotations: sharded over both device contexts iff the
-            # threshold allows it (tfhe_last_device_count, ABI v5)
-            assert multi.last_device_count() == (1 if split == 4096 else 2), split
+        want_all = K.ck.engine(0).wires_gather(np.arange(circ.num_wires, dtype=np.int32))
+        for exchange in (1, 2, 0):            # device-to-device copies / pinned host staging / by peer access
+            multi.set_option("level_exchange", exchange)
+            assert multi.get_option("level_exchange") == exchange
+            for split in (4096, 8, 2):        # never split at these sizes / only the 16-gate levels / everything but single gates
+                multi.set_option("level_split_min", split)
+                got = circ.run(K.ck, enc, device=[0, 0]).data
+                assert np.array_equal(got, want), (exchange, split)
+                # the last level of both circuits is 16 parallel MUXes = 32 rotations: sharded over both device contexts iff the
+                # threshold allows it (tfhe_last_device_count, ABI v5)
+                assert multi.last_device_count() == (1 if split == 4096 else 2), split
+                # every intermediate wire, read back through the first device (which fetches what the second one computed)
+                assert np.array_equal(multi.wires_gather(np.arange(circ.num_wires, dtype=np.int32)), want_all), (exchange, split)
     # a level of ONE gate is never sharded, whatever the threshold
     multi.set_option("level_split_min", 1)
     multi.wires_alloc(4)

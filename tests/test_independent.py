@@ -130,6 +130,10 @@ CASES = [  # N, k, l, beta, n
     (1024, 1, 3, 7, 2),               # tfhe_parameters_128's (api.jl:55-69)
     (1024, 2, 2, 10, 2),              # tlwe_mask_size = 2 (api.jl:30 keyword)
     (2048, 1, 3, 7, 2),               # BASELINE config 4b's synthetic N = 2048 shape
+    (512, 1, 2, 10, 3),               # any power-of-two N (api.jl:4-21 validates nothing): the any-N kernel (round 5)
+    (4096, 1, 3, 7, 2),
+    (256, 2, 2, 8, 2),
+    (1024, 5, 1, 8, 2),               # tlwe_mask_size beyond what blind_rotate_kernel_general holds
 ]
 
 

@@ -28,6 +28,24 @@ def _words(rng, rows, width):
     return x
 
 
+def _check_clock(eng, what):
+    """The in-kernel clock of the DIAG run that just finished (tfhe_last_kernel_clock_mhz).  A launch that lasted a millisecond or
+    more holds the sustained clock: 300 .. 2600 MHz on an MI355X.  The launches of this file's small cases last tens of
+    microseconds: their reading may sit on the DVFS ramp of a device that just woke up (the 300 MHz bound failed once there —
+    round-4 advice), and one whose workgroups ran for less than 10 us has no reading at all (TFHE_ERR_STATE): for those only
+    that the figure, if there is one, is a plausible frequency."""
+    import tfhe_jl_amd as tfhe
+    long_launch = eng.last_timing_ms(0) >= 1.0
+    try:
+        clock = eng.last_kernel_clock_mhz()
+    except tfhe.EngineError as e:
+        assert e.code == 5 and not long_launch, (what, str(e))
+        return None
+    lo, hi = (300.0, 2600.0) if long_launch else (30.0, 3000.0)
+    assert lo < clock < hi, (what, clock, long_launch)
+    return clock
+
+
 def _check(eng, K, x, expect_kernel, what):
     want = K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8)
     got = eng.bootstrap(MU, x, with_keyswitch=False)
@@ -37,12 +55,12 @@ def _check(eng, K, x, expect_kernel, what):
     try:
         again = eng.bootstrap(MU, x, with_keyswitch=False)
         assert eng.last_kernel_name() == expect_kernel
-        margin, clock = eng.last_rounding_margin(), eng.last_kernel_clock_mhz()
+        margin = eng.last_rounding_margin()
+        _check_clock(eng, what)
     finally:
         eng.set_option("measure_margin", 0)
     assert np.array_equal(again, want), what + " (DIAG instantiation)"
     assert 0.0 <= margin < 0.25, (what, margin)
-    assert 50.0 < clock < 3000.0, (what, clock)      # sanity only (300 .. 2600 failed once, on a very short kernel right after device start)
     return margin
 
 
@@ -261,12 +279,12 @@ def _mk_check(eng, o, x, y, expect_kernel):
     eng.set_option("measure_margin", 1)
     try:
         again = eng.mk_gate_nand(x, y)
-        margin, clock = eng.last_rounding_margin(), eng.last_kernel_clock_mhz()
+        margin = eng.last_rounding_margin()
+        _check_clock(eng, expect_kernel)
     finally:
         eng.set_option("measure_margin", 0)
     assert np.array_equal(again, want)
     assert 0.0 <= margin < 0.25, margin
-    assert 50.0 < clock < 3000.0, clock             # sanity only (300 .. 2600 failed once, on a very short kernel right after device start)
     return margin
 
 
@@ -314,7 +332,7 @@ def test_mk_general_kernel_margin(tfhe, orc, which, parties, l, beta, n):
 # ---- BASELINE configurations at their stated batch sizes ----------------------------------------------------------
 def test_config4a_128bit_4096(tfhe, orc, keys128):
     """BASELINE config 4a: tfhe_parameters_128 (api.jl:55-69), 4096 NAND on one GPU -> blind_rotate_kernel_v3<3,8,tw2reg,rw4>.
-    Every output decrypts to NAND; 64 sampled rows equal the oracle word for word; DIAG run identical, margin < 0.25."""
+    Every output decrypts to NAND; 256 sampled rows equal the oracle word for word; DIAG run identical, margin < 0.25."""
     K = keys128
     eng = K.ck.engine(0)
     rng = np.random.default_rng(4128)
@@ -325,8 +343,8 @@ def test_config4a_128bit_4096(tfhe, orc, keys128):
     got = eng.gates(ops, x, y)
     assert eng.last_kernel_name() == "blind_rotate_kernel_v3<3,8,tw2reg,rw4>"
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
-    idx = rng.choice(B, 64, replace=False)
-    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+    idx = rng.choice(B, 256, replace=False)            # >= 256 sampled rows against the oracle
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=orc.max_threads()))
     eng.set_option("measure_margin", 1)
     again = eng.gates(ops, x, y)
     margin = eng.last_rounding_margin()
@@ -348,8 +366,8 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
     got = eng.gates(ops, x, y)
     assert eng.last_kernel_name() == "blind_rotate_kernel_n2048x<3,rw2>"
     assert np.array_equal(tfhe.decrypt(K.sk, got), ~(bx & by))
-    idx = rng.choice(B, 64, replace=False)
-    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=16))
+    idx = rng.choice(B, 256, replace=False)            # >= 256 sampled rows against the oracle
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], x[idx], y[idx], nthreads=orc.max_threads()))
     for _ in range(2):                               # the same full launch again: every word identical (a race between the two
         assert np.array_equal(eng.gates(ops, x, y), got)   # waves of a rotation would show as a run-to-run difference)
     eng.set_option("br_prio_pct", 0)                 # without the issue-priority schedule: same words
@@ -368,7 +386,7 @@ def test_config4b_synthetic_n2048_4096(tfhe, orc):
 
 def test_config5_mk_two_party_1024(tfhe, orc):
     """BASELINE config 5: mktfhe_parameters_2party (mk_api.jl:4-10), 1024 NAND -> mk_blind_rotate_kernel_w2<4>.
-    64 sampled rows equal the oracle word for word (decrypt-level MK checks are ~0.2 %/gate noisy by design of the
+    256 sampled rows equal the oracle word for word (decrypt-level MK checks are ~0.2 %/gate noisy by design of the
     scheme's parameters, SURVEY §4: at least 98.5 % must decrypt to NAND)."""
     p = tfhe.mktfhe_parameters_2party
     rng = np.random.default_rng(321)
@@ -385,8 +403,8 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     got = eng.mk_gate_nand(x, y)
     assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w2<4>"
     assert (tfhe.mk_decrypt(sks, got) == ~(m1 & m2)).mean() >= 0.985
-    idx = rng.choice(B, 64, replace=False)
-    assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=16))
+    idx = rng.choice(B, 256, replace=False)            # >= 256 sampled rows against the oracle
+    assert np.array_equal(got[idx], o.mk_gate_nand(x[idx], y[idx], nthreads=orc.max_threads()))
     for _ in range(2):                               # the same full launch again: every word identical (no race between the waves)
         assert np.array_equal(eng.mk_gate_nand(x, y), got)
     eng.set_option("br_prio_pct", 0)                 # without the issue-priority schedule: same words

@@ -64,6 +64,10 @@ def test_blind_rotate_kernels_keep_two_waves_per_simd():
     assert not [k for k in rep if re.match(r"void blind_rotate_kernel<\d, 2>", k) or "blind_rotate_kernel_n2048<" in k]
     # (69 until the one- and two-waves-per-rotation kernels were also instantiated with the decomposition length as a run-time
     #  value, L = 0: seven kernels that give EVERY unshipped l at k = 1, N = 1024 the speed of the tuned ones)
-    assert len(rep) < 78, f"{len(rep)} kernels in the library"
+    #  round 5: + 7 for kernels_anyn.hpp — every parameter set outside N = 1024 / 2048, k <= 4, <= 8 parties: blind rotation
+    #  single- / multi-key with their DIAG instantiations, key preparation, spectra permutation, RGSW.Expand)
+    assert len(rep) < 86, f"{len(rep)} kernels in the library"
+    anyn = [k for k in rep if "anyn::" in k]
+    assert len(anyn) == 7 and all(rep[k]["scratch"] == 0 for k in anyn), anyn
     rt = [k for k in rep if re.search(r"void blind_rotate_kernel_(v3|w2)<0,", k)]
     assert len(rt) == 7 and all(rep[k]["scratch"] == 0 and rep[k]["occ"] >= 2 for k in rt), rt

@@ -22,8 +22,9 @@ ABI_SYMBOLS = [
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
     "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key", "tfhe_host_alloc", "tfhe_host_free",
     "tfhe_timing_history_ms", "tfhe_gates_batch_submit", "tfhe_gates_batch_wait", "tfhe_last_device_count",
+    "tfhe_get_option",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -108,6 +109,7 @@ def load():
     lib.tfhe_last_device_count.argtypes = [vp]
     lib.tfhe_last_device_count.restype = i32
     lib.tfhe_set_option.argtypes = [vp, C.c_char_p, i64]
+    lib.tfhe_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     lib.tfhe_last_rounding_margin.argtypes = [vp, C.POINTER(C.c_double)]
     lib.tfhe_wires_alloc.argtypes = [vp, i64]
     lib.tfhe_wires_upload.argtypes = [vp, i64, i64, vp]
@@ -421,3 +423,8 @@ class Engine:
 
     def set_option(self, name, value):
         self._check(self._lib.tfhe_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self._lib.tfhe_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value

@@ -107,13 +107,14 @@ class Circuit:
             eng.wires_upload(0, m)
         # no per-phase timing events while the levels run: each record keeps the stream's next kernel waiting ~5 us, and a level
         # of a narrow circuit is six short operations around one single-rotation kernel (tutorial circuit: 30.5 -> 30.1 ms)
+        timing_before = eng.get_option("timing_events")              # (the engine is shared through ck.engine(): put the caller's setting back)
         eng.set_option("timing_events", 0)
         try:
             for ops, a, b, c, out in self.level_arrays():
                 eng.gates_level(ops, a, b, c, out)
             return LweSampleArray(eng.wires_gather(self._outputs))     # one device gather + one copy for all outputs
         finally:
-            eng.set_option("timing_events", 1)
+            eng.set_option("timing_events", timing_before)
 
     def run_batch(self, ck, inputs, device=0):
         """The same circuit on M independent input sets at once: inputs int32 [M][n_inputs][n+1] (or a list of M LweSampleArrays),
@@ -135,12 +136,13 @@ class Circuit:
             eng.wires_upload(0, np.ascontiguousarray(m.transpose(1, 0, 2)).reshape(self._n_inputs * M, -1))
         inst = np.arange(M, dtype=np.int32)
         spread = lambda w: (w[:, None] * M + inst[None, :]).reshape(-1).astype(np.int32)      # wire ids -> rows, instance fastest
+        timing_before = eng.get_option("timing_events")
         eng.set_option("timing_events", 0)
         try:
             for ops, a, b, c, out in self.level_arrays():
                 eng.gates_level(np.repeat(ops, M), spread(a), spread(b), spread(c), spread(out))
             rows = eng.wires_gather(spread(np.asarray(self._outputs, np.int32)))
         finally:
-            eng.set_option("timing_events", 1)
+            eng.set_option("timing_events", timing_before)
         return np.ascontiguousarray(rows.reshape(len(self._outputs), M, -1).transpose(1, 0, 2))
 

@@ -2066,14 +2066,14 @@ __global__ __launch_bounds__(64) void mk_expand_kernel(MkExpandArgs A)
 
 // the party's own columns and the c0 / c1 rows are copies: x[jj, party] = d0[jj], y[jj, party] = d1[jj]  (:328-336)
 __global__ void mk_expand_copy_kernel(const int32_t *__restrict__ c0, const int32_t *__restrict__ c1, const int32_t *__restrict__ d0,
-                                      const int32_t *__restrict__ d1, int32_t *__restrict__ key, int n, int l, int parties, int party)
+                                      const int32_t *__restrict__ d1, int32_t *__restrict__ key, int n, int l, int parties, int party, int N = kN)
 {
     const int j = blockIdx.x, jj = blockIdx.y, which = blockIdx.z;       // which: 0 x, 1 y, 2 c0, 3 c1
     const int per = 2 * l * parties + 2 * l;
-    const int32_t *src = (which == 0 ? d0 : which == 1 ? d1 : which == 2 ? c0 : c1) + ((size_t)j * l + jj) * kN;
+    const int32_t *src = (which == 0 ? d0 : which == 1 ? d1 : which == 2 ? c0 : c1) + ((size_t)j * l + jj) * N;
     const int slot = which == 0 ? jj * parties + party : which == 1 ? l * parties + jj * parties + party : which == 2 ? 2 * l * parties + jj : 2 * l * parties + l + jj;
-    int32_t *dst = key + ((size_t)j * per + slot) * kN;
-    for (int t = threadIdx.x; t < kN; t += blockDim.x) dst[t] = src[t];
+    int32_t *dst = key + ((size_t)j * per + slot) * N;
+    for (int t = threadIdx.x; t < N; t += blockDim.x) dst[t] = src[t];
 }
 
 // The reference's stored spectra (natural frequency order, polynomials.jl:106-112) -> engine order.

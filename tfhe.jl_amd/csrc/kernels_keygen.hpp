@@ -85,17 +85,18 @@ __global__ __launch_bounds__(256) void bk_kernel(Args A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *a_lds = reinterpret_cast<uint32_t *>(smem);                 // [k][N]
-    uint32_t *s_bits = a_lds + (size_t)A.k * A.N;                         // [k][N/32]
+    uint32_t *s_bits = a_lds + (size_t)A.k * A.N;                         // [k][ceil(N/32)]
     const int N = A.N, k = A.k, tid = threadIdx.x;
+    const int NW = (N + 31) / 32;                                         // key-bit words per polynomial (N < 32: one, partly filled)
     const size_t r = blockIdx.x;                                          // sample = (i * l + p) * (k+1) + j
     const int j = (int)(r % (size_t)(k + 1));
     const int p = (int)((r / (size_t)(k + 1)) % (size_t)A.l);
     const size_t i = r / ((size_t)(k + 1) * A.l);
     int32_t *out = A.bk + r * (size_t)(k + 1) * N;
-    for (int w = tid; w < k * (N / 32); w += 256) {
-        const int c = w / (N / 32), w0 = w % (N / 32);
+    for (int w = tid; w < k * NW; w += 256) {
+        const int c = w / NW, w0 = w % NW;
         uint32_t bits = 0;
-        for (int b = 0; b < 32; b++) bits |= (uint32_t)(A.tlwe_key[c * N + w0 * 32 + b] & 1) << b;
+        for (int b = 0; b < 32 && w0 * 32 + b < N; b++) bits |= (uint32_t)(A.tlwe_key[c * N + w0 * 32 + b] & 1) << b;
         s_bits[w] = bits;
     }
     for (int e = tid; e < k * N; e += 256) {
@@ -109,14 +110,14 @@ __global__ __launch_bounds__(256) void bk_kernel(Args A)
         uint32_t acc = dtot32(gaussian(2u, r * (uint64_t)N + co, A.seed) * A.bs_alpha);
         for (int c = 0; c < k; c++) {
             const uint32_t *a = a_lds + c * N;
-            for (int w0 = 0; w0 < N / 32; w0++) {
+            for (int w0 = 0; w0 < NW; w0++) {
                 // Every bit position is visited and its term masked in or out: the trip count, the LDS addresses and the
                 // instruction stream do not depend on the secret key bits (a `while (bits)` loop over the set bits would
                 // make the kernel's duration a function of the key's Hamming weight per word).
-                const uint32_t bits = s_bits[c * (N / 32) + w0];
+                const uint32_t bits = s_bits[c * NW + w0];
 #pragma unroll 8
                 for (int b = 0; b < 32; b++) {
-                    const int idx = co - (w0 * 32 + b);                   // X^m * a: coefficient co takes a[co - m], negated on wrap
+                    const int idx = co - (w0 * 32 + b);                   // X^m * a: coefficient co takes a[co - m], negated on wrap (m < N: the bits past N are zero)
                     const uint32_t v = a[idx & (N - 1)];
                     const uint32_t take = 0u - ((bits >> b) & 1u);        // all ones where key bit m is set
                     acc += (idx < 0 ? 0u - v : v) & take;

@@ -7,27 +7,35 @@
 
 using namespace tfhe;
 
-// keyswitch.jl:45-80.  One workgroup per output sample; thread w owns words w, w + blockDim, ...
+// keyswitch.jl:45-80, any base / decomposition length / sample size.  One workgroup per (output sample, chunk of 1024 output
+// words); thread w owns words w, w + 256, ... of its chunk.
 // Input sample = ext[e0] (+ ext[e1] + (0, 2^29) for MUX, gates.jl:174).
 struct KsArgs {
-    const int32_t *ext;     // [R][kN+1]
+    const int32_t *ext;     // [R][in_stride]
     const int32_t *ks;      // [kN][t][base-1][n+1]
     const int32_t *e0;      // [G] index into ext
     const int32_t *e1;      // [G] second index or -1
     const int32_t *dst;     // [G] output gate index (NULL: identity)
-    int32_t *out;           // [B][n+1]
+    int32_t *out;           // [B][out_stride]
     int32_t n, kN, t, log2_base;
+    // generalised addressing (single key: in_stride = kN+1, in_off = 0, in_b = kN, out_stride = n+1, out_off = 0, out_b = n;
+    // multi-key party p (mk_internals.jl:397-411): in_off = p*N, in_b = P*N, out_off = p*n, out_b = P*n)
+    int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
+    int32_t add_b;          // 1: out[out_b] = ext b (+ MUX constant) - sum; 0 (multi-key party > 0): accumulate into out[out_b]
 };
 
-template <int WPT>  // words per thread
+constexpr int KS1_WPT = 4;  // words per thread: a workgroup covers 1024 output words
+
 __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
 {
+    constexpr int WPT = KS1_WPT;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     const int n1 = P.n + 1;
-    const int32_t *x0 = P.ext + (size_t)P.e0[g] * (P.kN + 1);
+    const int w0 = blockIdx.y * (256 * WPT);                                  // first word of this workgroup's chunk
+    const int32_t *x0 = P.ext + (size_t)P.e0[g] * P.in_stride;
     const int e1 = P.e1 ? P.e1[g] : -1;
-    const int32_t *x1 = e1 >= 0 ? P.ext + (size_t)e1 * (P.kN + 1) : nullptr;
+    const int32_t *x1 = e1 >= 0 ? P.ext + (size_t)e1 * P.in_stride : nullptr;
     const int base1 = (1 << P.log2_base) - 1;
     const uint32_t prec_offset = 1u << (32 - (1 + P.log2_base * P.t));       // keyswitch.jl:58
 
@@ -36,8 +44,8 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
     for (int u = 0; u < WPT; u++) accw[u] = 0;
 
     for (int i = 0; i < P.kN; i++) {
-        uint32_t ai = (uint32_t)x0[i];
-        if (x1) ai += (uint32_t)x1[i];
+        uint32_t ai = (uint32_t)x0[P.in_off + i];
+        if (x1) ai += (uint32_t)x1[P.in_off + i];
         const int32_t aibar = (int32_t)(ai + prec_offset);                  // keyswitch.jl:59
         const int32_t *rows_i = P.ks + (size_t)i * P.t * base1 * n1;
         for (int j = 1; j <= P.t; j++) {
@@ -46,24 +54,28 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
                 const int32_t *row = rows_i + (size_t)((j - 1) * base1 + (d - 1)) * n1;
 #pragma unroll
                 for (int u = 0; u < WPT; u++) {
-                    const int wd = tid + u * 256;
+                    const int wd = w0 + tid + u * 256;
                     if (wd < n1) accw[u] -= (uint32_t)row[wd];               // keyswitch.jl:74
                 }
             }
         }
     }
     const size_t og = P.dst ? (size_t)P.dst[g] : (size_t)g;
-    int32_t *o = P.out + og * n1;
+    int32_t *o = P.out + og * P.out_stride;
 #pragma unroll
     for (int u = 0; u < WPT; u++) {
-        const int wd = tid + u * 256;
-        if (wd < n1) {
+        const int wd = w0 + tid + u * 256;
+        if (wd < P.n) {
+            o[P.out_off + wd] = (int32_t)accw[u];
+        } else if (wd == P.n) {
             uint32_t v = accw[u];
-            if (wd == P.n) {                                                 // keyswitch.jl:50
-                v += (uint32_t)x0[P.kN];
-                if (x1) v += (uint32_t)x1[P.kN] + (1u << 29);                // gates.jl:174
+            if (P.add_b) {                                                   // keyswitch.jl:50
+                v += (uint32_t)x0[P.in_b];
+                if (x1) v += (uint32_t)x1[P.in_b] + (1u << 29);              // gates.jl:174
+            } else {
+                v += (uint32_t)o[P.out_b];                                   // mk_internals.jl:409 (launches are stream-ordered)
             }
-            o[wd] = (int32_t)v;
+            o[P.out_b] = (int32_t)v;
         }
     }
 }

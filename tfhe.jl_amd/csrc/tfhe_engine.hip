@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,6 +41,7 @@ using namespace tfhe;
 #ifndef TFHE_NO_G2
 #include "mk_g2_launch.hpp"
 #endif
+#include "kernels_anyn.hpp"
 #include "kernels_keyswitch.hpp"
 #include "kernels_keygen.hpp"
 
@@ -62,6 +66,23 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Rows of the wire table travelling from one device of a multi-device context to another (pull_wires).  A small ring of
+// slots per ordered pair, each with its own buffers and events, so that a level can queue its transfers while those of the
+// previous levels are still in flight; the host waits only if the ring wraps onto a slot whose transfer has not finished.
+struct PairXfer {
+    static constexpr int kSlots = 4;
+    struct Slot {
+        DevBuf out, idx_src;          // on the source device: the gathered rows, their wire indices
+        DevBuf in, idx_dst;           // on the destination device: the rows as they arrive, their wire indices
+        int32_t *h_idx = nullptr; size_t h_idx_cap = 0;     // pinned staging of the indices (read by both uploads)
+        void *h_rows = nullptr; size_t h_rows_cap = 0;      // pinned staging of the rows (host path only)
+        hipEvent_t ready = nullptr;   // recorded on the source's stream: rows gathered (host path: and copied out)
+        hipEvent_t taken = nullptr;   // recorded on the destination's stream: rows scattered into its table
+        bool pending = false;         // `taken` recorded and not yet known to have completed
+    } slot[kSlots];
+    unsigned next = 0;
+};
+
 struct tfhe_ctx {
     tfhe_params P{};
     int device = 0;
@@ -72,7 +93,7 @@ struct tfhe_ctx {
     hipStream_t stream = nullptr;
     // Timing events of the last kTimingSlots batch calls (batch start, BR start / end (= KS start), KS end): a caller that
     // times a sequence of calls reads them all afterwards (tfhe_timing_history_ms) instead of synchronising after each
-    static constexpr int kTimingSlots = 32;
+    static constexpr int kTimingSlots = 33;      // 32 reportable sets + the one being recorded
     hipEvent_t evring[kTimingSlots][4] = {};
     hipEvent_t *ev = evring[0];          // the current call's set
     int64_t timed_calls = 0;             // batch calls that recorded a set so far
@@ -100,6 +121,19 @@ struct tfhe_ctx {
     cplx *d_tables = nullptr;   // tw1[512] | tw2[64] | twist[512]
     Tables T{};
     Gadget g{};
+    // any-N kernels (kernels_anyn.hpp): e^{-2 pi i t/M} [M] | e^{-i pi j/N} [M] for THIS context's N
+    cplx *d_anyn_tab = nullptr;
+    int br_anyn = 0;             // tfhe_set_option("br_anyn", 1): the any-N kernel (and its key layout) even where a tuned kernel exists; before the key is loaded
+    int anyn_spec = -1;          // any-N kernel: spectrum accumulators in LDS (0) / in global memory (1) / LDS when they fit (-1)
+    // Parameter sets outside what the tuned kernels and blind_rotate_kernel_general are built for (N other than 1024 / 2048,
+    // k > 4; multi-key: N other than 1024, more than 8 parties, l > 8) run on the any-N kernels, which need the key in their
+    // own spectrum order: decided once, consulted by the loaders and the dispatcher
+    bool anyn() const
+    {
+        if (br_anyn) return true;
+        if (P.parties > 1) return P.N != kN || P.parties > 8 || P.bs_l > 8;
+        return (P.N != kN && P.N != 2048) || P.k > 4;
+    }
 
     // keys (only the layout of the selected keyswitch kernel family stays resident)
     cplx *d_bk = nullptr;       size_t bk_polys = 0;
@@ -119,7 +153,7 @@ struct tfhe_ctx {
     int32_t *d_wires = nullptr; int64_t num_wires = 0;
 
     // workspaces
-    DevBuf bara, ext, map, io[4], diag, abar, mk_acc;
+    DevBuf bara, ext, map, io[4], diag, abar, mk_acc, spec;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
     int n2048_rw = 0;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 0|1|2); 0 = one up to
@@ -137,7 +171,14 @@ struct tfhe_ctx {
     bool borrows_keys = false;
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
     uint32_t submits = 0;
-    std::vector<uint8_t> wire_stale;      // multi-device context: wires whose current value is on the first device only (written by a level that ran there)
+    // multi-device context: coherence of the replicated wire table.  wire_valid[k][w]: device k's replica holds wire w's
+    // current value; wire_owner[w]: a device that does (the one that wrote it last).  A level's outputs become valid on the
+    // device that computed them only; whoever reads them elsewhere later fetches them then (pull_wires), device to device.
+    std::vector<std::vector<uint8_t>> wire_valid;
+    std::vector<int32_t> wire_owner;
+    std::vector<uint8_t> peer_ok;         // [nk * nk]: device-to-device copies allowed between kids' devices (hipDeviceCanAccessPeer, or the same device)
+    std::vector<struct PairXfer *> xfer;  // [nk * nk] rows in flight from kid src to kid dst (made on first use)
+    int level_exchange = 0;               // multi-device context: how a sharded level's rows reach the other replicas: 0 = device-to-device copies where hipDeviceCanAccessPeer allows (else pinned host staging), 1 = device-to-device, 2 = host staging
     int64_t level_split_min = 4096;       // multi-device context: levels of at least this many blind rotations are sharded over the devices (tfhe_set_option("level_split_min", n); < 0: never)
     std::vector<int32_t> kid_tickets[2];  // multi-device context: per submit slot, the ticket every kid gave for its shard (2: none)
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
@@ -148,6 +189,11 @@ struct tfhe_ctx {
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
     void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
     hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
+
+    // "calls on one context must not overlap": the thread inside an entry point owns the context (CallGuard below); a second
+    // thread's overlapping call gets TFHE_ERR_STATE instead of racing on the shared workspaces
+    std::atomic<std::thread::id> owner{};
+    int owner_depth = 0;
 
     bool multi() const { return !kids.empty(); }
 
@@ -168,6 +214,61 @@ struct tfhe_ctx {
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess)                                                                      \
             return (ctx)->set_err(TFHE_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+
+// ---- one caller at a time ------------------------------------------------------------------------------------------
+// Every entry point that takes a (non-const) context enters through CallGuard.  The first thread in becomes the owner until its
+// outermost call returns (entry points call one another: the owner may nest); any other thread's call fails with TFHE_ERR_STATE
+// and a message that tfhe_last_error() returns to THAT thread (the context's own message string belongs to the owner).
+// Streaming stays what it was: tfhe_gates_batch_submit returns while the batch runs on the device; the guard covers the host side.
+static thread_local const tfhe_ctx *g_rejected_ctx = nullptr;
+static const char kBusyMessage[] = "the context is inside another call on another thread: calls on one context must not overlap (one caller at a time; use one context per thread)";
+struct CallGuard {
+    tfhe_ctx *c;
+    bool ok;
+    explicit CallGuard(tfhe_ctx *c_) : c(c_), ok(false)
+    {
+        const std::thread::id me = std::this_thread::get_id();
+        if (c->owner.load(std::memory_order_acquire) == me) { c->owner_depth++; ok = true; return; }
+        std::thread::id none{};
+        ok = c->owner.compare_exchange_strong(none, me, std::memory_order_acq_rel);
+        if (ok) { c->owner_depth = 1; if (g_rejected_ctx == c) g_rejected_ctx = nullptr; }
+        else g_rejected_ctx = c;
+    }
+    ~CallGuard()
+    {
+        if (ok && --c->owner_depth == 0) c->owner.store(std::thread::id{}, std::memory_order_release);
+    }
+    CallGuard(const CallGuard &) = delete;
+    CallGuard &operator=(const CallGuard &) = delete;
+};
+#define ENTER_CTX(ctx)                                                                             \
+    if (!(ctx)) return TFHE_ERR_INVALID_ARG;                                                       \
+    CallGuard call_guard_(ctx);                                                                    \
+    if (!call_guard_.ok) return TFHE_ERR_STATE
+
+// ---- hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel), never lowered ---------------------------
+// A driver call on the host side of every launch of a kernel that needs more than 64 KB of LDS — on the path where latency is
+// the metric (a single gate, a circuit level).  The attribute belongs to (device, function), is shared by every context of the
+// process and only ever needs to grow (the any-N kernels' LDS depends on the parameter set), so the largest value set so far
+// is remembered process-wide.
+static int32_t ensure_dyn_lds(tfhe_ctx *c, const void *fn, size_t bytes, const char *what)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> have;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &cur = have[std::make_pair(c->device, fn)];
+    if (cur >= bytes) return TFHE_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return c->set_err(TFHE_ERR_DEVICE, "hipFuncSetAttribute(%s, %zu bytes of LDS) failed: %s", what, bytes, hipGetErrorString(e));
+    cur = bytes;
+    return TFHE_OK;
+}
+#define LDS_TRY(ctx, bytes, ...)                                                                   \
+    do {                                                                                           \
+        const int32_t rl_ = ensure_dyn_lds(ctx, (const void *)(__VA_ARGS__), (size_t)(bytes), #__VA_ARGS__); \
+        if (rl_) return rl_;                                                                       \
     } while (0)
 
 constexpr size_t kH2TableOffset = kTableElems + 1024;      // tw1h | tw2q | tw3q of blind_rotate_kernel_h2
@@ -232,7 +333,12 @@ int32_t tfhe_device_count(void)
     return n;
 }
 
-const char *tfhe_last_error(const tfhe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *tfhe_last_error(const tfhe_ctx *ctx)
+{
+    if (!ctx) return g_create_error.c_str();
+    if (g_rejected_ctx == ctx) return kBusyMessage;      // this thread's last call on ctx was refused because another thread was inside one
+    return ctx->err.c_str();
+}
 
 int32_t tfhe_shard_bounds(const uint8_t *opcodes, int64_t B, int32_t shards, int64_t *bounds)
 {
@@ -253,21 +359,19 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: parameters must be positive and N a power of two");
     if (p.bs_l * p.bs_log2_base > 32) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: bs_l * bs_log2_base > 32");
     if (p.ks_t * p.ks_log2_base > 31) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: ks_t * ks_log2_base > 31");
-    if (p.N != kN && p.N != kN2) {
-        snprintf(buf, sizeof buf, "tfhe_ctx_create: this build supports N = %d or %d (got %d)", kN, kN2, p.N);
+    // Every parameter set the reference would accept is accepted (SchemeParameters is an unvalidated positional struct and
+    // tlwe_mask_size a free keyword, api.jl:4-21,30,55; the transform works for any even length, polynomials.jl:44-58): tuned
+    // kernels where one was instantiated (launch_blind_rotate_part), blind_rotate_kernel_general for the other shapes at
+    // N = 1024 / 2048 with k <= 4, the any-N kernels (kernels_anyn.hpp) for everything else.  What remains refused:
+    //   * N > 8192: one polynomial's transform buffer and digit words no longer fit the 160 KB of LDS of a CU (and the
+    //     Float64 transform of the reference itself has lost its exactness long before: polynomials.jl:115-116);
+    //   * multi-key with tlwe_mask_size != 1: the reference's multi-key code hard-wires k = 1 (mk_internals.jl:89-91,129-131).
+    if (p.N > 8192) {
+        snprintf(buf, sizeof buf, "tfhe_ctx_create: N = %d > 8192 unsupported (one polynomial's transform no longer fits a CU's LDS)", p.N);
         return fail(TFHE_ERR_UNSUPPORTED, buf);
     }
-    // Single key: every (k <= 4, l with l * beta <= 32, N in {1024, 2048}) runs — on a tuned kernel where one was
-    // instantiated (k <= 2 with l = 2 or 3 at N = 1024; k = 1, l = 3 at N = 2048), on blind_rotate_kernel_general otherwise:
-    // SchemeParameters is unvalidated and tlwe_mask_size a free keyword in the reference (api.jl:4-21,30,55).
-    if (p.N == kN2 && p.parties != 1)
-        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key is supported with N = 1024 only (the reference ships no other multi-key set, mk_api.jl:4-34)");
-    if (p.k > 4) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: tlwe_mask_size k > 4 unsupported");
     if (p.k != 1 && p.parties != 1) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: multi-key needs tlwe_mask_size 1 (as the reference, mk_internals.jl:89-91)");
-    if (p.parties > 1 && p.bs_l > 8)
-        return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: bs_decomp_length > 8 (multi-key) unsupported");
-    if (p.parties > 8) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: more than 8 parties unsupported");
-    if (p.n + 1 > 1024) return fail(TFHE_ERR_UNSUPPORTED, "tfhe_ctx_create: lwe_size + 1 > 1024 unsupported");
+    if (p.n > (1 << 24) || p.k > 1024 || p.parties > 1024) return fail(TFHE_ERR_INVALID_ARG, "tfhe_ctx_create: lwe_size, tlwe_mask_size or max_parties beyond any plausible value");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -306,6 +410,20 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return bail(e, "hipMemcpy(tables)");
     c->T = tables_from(c->d_tables);
+    {   // the any-N kernels' tables for this context's N: e^{-2 pi i t/M} | e^{-i pi j/N}, M = N/2 (long double on the host)
+        const int M = p.N / 2;
+        std::vector<cplx> ht((size_t)2 * M);
+        const long double pi = 3.14159265358979323846264338327950288L;
+        for (int t = 0; t < M; t++) {
+            const long double a = -2.0L * pi * (long double)t / (long double)M, b = -pi * (long double)t / (long double)p.N;
+            ht[(size_t)t] = mk((double)cosl(a), (double)sinl(a));
+            ht[(size_t)M + t] = mk((double)cosl(b), (double)sinl(b));
+        }
+        if ((e = hipMalloc((void **)&c->d_anyn_tab, ht.size() * sizeof(cplx))) != hipSuccess) return bail(e, "hipMalloc(any-N tables)");
+        if ((e = hipMemcpyAsync(c->d_anyn_tab, ht.data(), ht.size() * sizeof(cplx), hipMemcpyHostToDevice, c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return bail(e, "hipMemcpy(any-N tables)");
+    }
     *out_ctx = c;
     return TFHE_OK;
 }
@@ -347,6 +465,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->done_pending && c->done_ev) (void)hipEventSynchronize(c->done_ev);      // a call still running on a caller's stream
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_anyn_tab) (void)hipFree(c->d_anyn_tab);
     if (c->borrows_keys) c->d_bk = nullptr, c->d_ks = nullptr, c->d_ksp = nullptr, c->d_ks4 = nullptr;      // the owner frees them
     if (c->d_bk) (void)hipFree(c->d_bk);
     if (c->d_ks) (void)hipFree(c->d_ks);
@@ -356,7 +475,7 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ks4) (void)hipFree(c->d_mk_ks4);
     if (c->d_mk_bk) (void)hipFree(c->d_mk_bk);
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
-    c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release(); c->mk_acc.release();
+    c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release(); c->mk_acc.release(); c->spec.release();
     for (auto &b : c->io) b.release();
     if (c->h_map) (void)hipHostFree(c->h_map);
     for (auto &set : c->evring)
@@ -482,6 +601,7 @@ static void quiesce(tfhe_ctx *c)
 
 static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bool is_c128)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!host) return c->set_err(TFHE_ERR_INVALID_ARG, "load_bootstrap_key: NULL key pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_bootstrap_key: context is multi-key, use tfhe_mk_load_*");
@@ -496,7 +616,21 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     void *d_in = nullptr;
     HIP_TRY(c, hipMalloc(&d_in, bytes_in));
     hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyDefault, c->stream)   /* host pointer, or a device buffer (tfhe_keygen_cloud_key) */;
-    if (e == hipSuccess) {
+    if (e == hipSuccess && c->anyn()) {
+        // the any-N kernels' spectrum order (kernels_anyn.hpp): the same forward transform they run, or a permutation of the reference's spectra
+        const int log2N = ilog2i(c->P.N), M = c->P.N / 2;
+        if (is_c128) {
+            const size_t total = npolys * (size_t)M;
+            hipLaunchKernelGGL(anyn::bk_permute_c128_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const cplx *)d_in, c->d_bk, log2N - 1, total);
+        } else {
+            const size_t ldsp = (size_t)anyn::padded_len(M > 0 ? M : 1) * sizeof(cplx);
+            if (ldsp > 64 * 1024 && ensure_dyn_lds(c, (const void *)anyn::bk_prepare_kernel, ldsp, "anyn::bk_prepare_kernel")) e = hipErrorInvalidValue;
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(anyn::bk_prepare_kernel, dim3((unsigned)npolys), dim3((unsigned)anyn::threads_for(c->P.N)), ldsp, c->stream, (const int32_t *)d_in, c->d_bk,
+                                   (const cplx *)c->d_anyn_tab, (const cplx *)(c->d_anyn_tab + M), log2N, 1.0 / (double)M);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+    } else if (e == hipSuccess) {
         if (big && is_c128)
             hipLaunchKernelGGL(bk_permute_c128_kernel_n2048, dim3((unsigned)npolys), dim3(128), 0, c->stream, (const cplx *)d_in, c->d_bk);
         else if (big)
@@ -518,12 +652,14 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
 
 int32_t tfhe_load_bootstrap_key_i32(tfhe_ctx *c, const int32_t *bk)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     return load_bk_common(c, bk, bk_poly_count(c->P) * (size_t)c->P.N * sizeof(int32_t), false);
 }
 
 int32_t tfhe_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     return load_bk_common(c, bk_spectra, bk_poly_count(c->P) * (size_t)(c->P.N / 2) * sizeof(cplx), true);
 }
@@ -547,6 +683,7 @@ static int pick_ks_mode(const tfhe_ctx *c)
 
 int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "load_keyswitch_key: NULL key pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "load_keyswitch_key: context is multi-key, use tfhe_mk_load_*");
@@ -602,6 +739,7 @@ int32_t tfhe_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks)
 int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t *tlwe_key, double bs_noise_stddev,
                               double ks_noise_stddev, const uint32_t *seed, int32_t *bk_out, int32_t *ks_out)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!lwe_key || !tlwe_key || !seed) return c->set_err(TFHE_ERR_INVALID_ARG, "keygen_cloud_key: NULL key or seed pointer");
     if (c->P.parties != 1) return c->set_err(TFHE_ERR_STATE, "keygen_cloud_key: context is multi-key (use tfhe_mk_expand_load_bootstrap_key)");
@@ -636,7 +774,7 @@ int32_t tfhe_keygen_cloud_key(tfhe_ctx *c, const int32_t *lwe_key, const int32_t
         A.bs_alpha = bs_noise_stddev; A.ks_alpha = ks_noise_stddev;
         for (int i = 0; i < 6; i++) A.seed.w[i] = seed[i];
         const size_t samples = (size_t)P.n * P.bs_l * (P.k + 1);
-        const size_t lds = kN * 4 + (size_t)P.k * (P.N / 32) * 4;
+        const size_t lds = kN * 4 + (size_t)P.k * ((P.N + 31) / 32) * 4;
         hipLaunchKernelGGL(keygen::bk_kernel, dim3((unsigned)samples), dim3(256), lds, g->stream, A);
         hipLaunchKernelGGL(keygen::ks_noise_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, g->stream, A, Q);
         hipLaunchKernelGGL(keygen::ks_mean_kernel, dim3(1), dim3(256), 0, g->stream, A, Q);
@@ -726,6 +864,36 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
     a.R = (int32_t)R;
     const int L = c->P.bs_l;
     a.l = L;
+    if (c->anyn()) {
+        // any power-of-two N, any k, any l: one workgroup per rotation, in-LDS mixed-radix transforms (kernels_anyn.hpp)
+        const int K1 = c->P.k + 1, N = c->P.N, M = N / 2;
+        anyn::Args g;
+        g.diag = a.diag; g.bara = a.bara; g.bk = a.bk; g.ext = a.ext; g.g = c->g; g.n = a.n; g.mu = mu; g.K1 = K1; g.L = L; g.R = (int32_t)R;
+        g.log2N = ilog2i(N); g.parties = 1;
+        g.wtab = c->d_anyn_tab; g.twist = c->d_anyn_tab + M;
+        HIP_TRY(c, c->mk_acc.reserve((first + R) * (size_t)K1 * N * sizeof(int32_t)));
+        g.acc = (int32_t *)c->mk_acc.p + first * (size_t)K1 * N;
+        // spectrum accumulators in LDS when the whole workgroup fits a CU's 160 KB, in global memory otherwise
+        const bool fits = anyn::lds_bytes(N, K1) <= 160 * 1024;
+        const bool spec_lds = c->anyn_spec < 0 ? fits : (c->anyn_spec == 0 && fits);
+        g.spec_g = nullptr;
+        if (!spec_lds) {
+            HIP_TRY(c, c->spec.reserve((first + R) * (size_t)K1 * (M > 0 ? M : 1) * sizeof(cplx)));
+            g.spec_g = (cplx *)c->spec.p + first * (size_t)K1 * (M > 0 ? M : 1);
+        }
+        const size_t ldsa = anyn::lds_bytes(N, spec_lds ? K1 : 0);
+        const unsigned nt = (unsigned)anyn::threads_for(N);
+        if (dg) {
+            if (ldsa > 64 * 1024) LDS_TRY(c, ldsa, anyn::blind_rotate_kernel<true>);
+            hipLaunchKernelGGL((anyn::blind_rotate_kernel<true>), dim3((unsigned)R), dim3(nt), ldsa, s, g);
+        } else {
+            if (ldsa > 64 * 1024) LDS_TRY(c, ldsa, anyn::blind_rotate_kernel<false>);
+            hipLaunchKernelGGL((anyn::blind_rotate_kernel<false>), dim3((unsigned)R), dim3(nt), ldsa, s, g);
+        }
+        HIP_TRY(c, hipGetLastError());
+        name_kernel(c, spec_lds ? "blind_rotate_kernel_anyn(N=%d,k=%d,l=%d)" : "blind_rotate_kernel_anyn(N=%d,k=%d,l=%d,spec=global)", N, c->P.k, L);
+        return TFHE_OK;
+    }
     const bool tuned = c->P.N == kN2 ? (c->P.k == 1 && L == 3) : c->P.k == 1 ? true : (c->P.k == 2 && (L == 2 || L == 3));
     if (!tuned || c->br_general) {
         // any (k <= 4, l, N): one wave per rotation, accumulator images in global memory, spectrum accumulators in LDS
@@ -741,7 +909,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 #define LAUNCH_GEN(NB, DG)                                                                                         \
         do {                                                                                                       \
             if (ldsg > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_general<NB, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
+                LDS_TRY(c, ldsg, blind_rotate_kernel_general<NB, DG>); \
             hipLaunchKernelGGL((blind_rotate_kernel_general<NB, DG>), dim3((unsigned)R), dim3(64), ldsg, s, g);     \
         } while (0)
         if (c->P.N == kN2) { if (dg) LAUNCH_GEN(32, true); else LAUNCH_GEN(32, false); }
@@ -764,7 +932,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 #define LAUNCH_2048(DG, RWV)                                                                                       \
         do {                                                                                                       \
             if (ldsb > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_n2048x<3, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+                LDS_TRY(c, ldsb, blind_rotate_kernel_n2048x<3, DG, RWV>); \
             hipLaunchKernelGGL((blind_rotate_kernel_n2048x<3, DG, RWV>), dim3(nblk), dim3(128 * RWV), ldsb, s, b); \
         } while (0)
         if (dg) LAUNCH_2048(true, 1);
@@ -796,7 +964,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
             a.grp_big = (int32_t)(R % G);
 #define LAUNCH_K2(LL)                                                                                              \
             do {                                                                                                   \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_k2<LL, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(7 * ldsk))); \
+                LDS_TRY(c, (7 * ldsk), blind_rotate_kernel_k2<LL, false, 7>); \
                 hipLaunchKernelGGL((blind_rotate_kernel_k2<LL, false, 7>), dim3((unsigned)G), dim3(448), 7 * ldsk, s, a); \
             } while (0)
             BR_CASES(LAUNCH_K2)
@@ -822,7 +990,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         const size_t ldsh = 2 * kImg * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx);
 #define LAUNCH_H2_(LL, DG)                                                                                         \
         do {                                                                                                       \
-            HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_h2<LL, DG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh)); \
+            LDS_TRY(c, ldsh, blind_rotate_kernel_h2<LL, DG>); \
             hipLaunchKernelGGL((blind_rotate_kernel_h2<LL, DG>), dim3((unsigned)R), dim3(256 * LL), ldsh, s, a, ht); \
         } while (0)
 #define LAUNCH_H2(LL) do { if (dg) LAUNCH_H2_(LL, true); else LAUNCH_H2_(LL, false); } while (0)
@@ -860,7 +1028,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         const bool group = c->v3_rw == 4 || (c->v3_rw == 0 && R >= 1536);      // (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
 #define LAUNCH_V3_GROUP(LL, DG)                                                                                    \
         do {                                                                                                       \
-            HIP_TRY(c, hipFuncSetAttribute((const void *)blind_rotate_kernel_v3<LL, 8, true, DG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds3))); \
+            LDS_TRY(c, (4 * lds3), blind_rotate_kernel_v3<LL, 8, true, DG, 4>); \
             hipLaunchKernelGGL((blind_rotate_kernel_v3<LL, 8, true, DG, 4>), dim3((unsigned)((R + 3) / 4)), dim3(256), 4 * lds3, s, a); \
         } while (0)
 #define LAUNCH_V3(LL)                                                                                              \
@@ -936,7 +1104,9 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     if (rc) return rc;
     std::vector<size_t> seg;                                   // rotations per launch, in order
     const bool tuned_l = c->P.bs_l == 2 || c->P.bs_l == 3;
-    if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7)) {
+    if (c->anyn()) {
+        // one launch
+    } else if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7)) {
         seg = k2_partition(R, (size_t)c->cu_count);
     } else if (c->br_split && !c->br_general && c->P.N == kN && c->P.k == 1 && c->br_small > 0) {      // (any l: the run-time-l instantiations)
         const size_t resident = 8 * (size_t)c->cu_count;      // rotations of blind_rotate_kernel_v3 on the chip
@@ -966,6 +1136,7 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
     k.out = out;
     k.n = c->P.n; k.kN = c->P.k * c->P.N; k.t = c->P.ks_t; k.log2_base = c->P.ks_log2_base;
     const int n1 = c->P.n + 1;
+    k.in_stride = k.kN + 1; k.in_off = 0; k.in_b = k.kN; k.out_stride = n1; k.out_off = 0; k.out_b = c->P.n; k.add_b = 1;
     if (c->ks_mode == 4) {
         Ks4Args a4;
         a4.ext = ext; a4.bmat = (const i32x4 *)c->d_ks4; a4.e0 = e0; a4.e1 = e1; a4.dst = dst; a4.out = out;
@@ -1000,9 +1171,7 @@ static int32_t launch_keyswitch(tfhe_ctx *c, size_t G, const int32_t *e0, const 
         HIP_TRY(c, hipGetLastError());
         return TFHE_OK;
     }
-    if (n1 <= 256) hipLaunchKernelGGL((keyswitch_kernel<1>), dim3((unsigned)G), dim3(256), 0, s, k);
-    else if (n1 <= 512) hipLaunchKernelGGL((keyswitch_kernel<2>), dim3((unsigned)G), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((keyswitch_kernel<4>), dim3((unsigned)G), dim3(256), 0, s, k);
+    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)G, (unsigned)((n1 + 256 * KS1_WPT - 1) / (256 * KS1_WPT))), dim3(256), 0, s, k);     // any base, t, n
     HIP_TRY(c, hipGetLastError());
     return TFHE_OK;
 }
@@ -1171,6 +1340,7 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
 int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *d_in0, const int32_t *d_in1,
                              const int32_t *d_in2, int32_t *d_out, int64_t B, void *stream)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (c->multi()) {
         if (c->kids.size() != 1) return c->set_err(TFHE_ERR_STATE, "gates_batch_dev: device pointers belong to one device; use tfhe_gates_batch on a multi-device context");
@@ -1189,14 +1359,22 @@ int32_t tfhe_gates_batch_dev(tfhe_ctx *c, const uint8_t *opcodes, const int32_t 
 }
 
 // ---- levelised circuit execution on a device-resident wire table -------------------------
-// On a multi-device context every device holds a replica of the wire table; multi_gates_level keeps the replicas coherent
-// (narrow levels on the first device, wide levels sharded, written wires exchanged through host memory).
+// On a multi-device context every device holds a replica of the wire table; the context tracks which replicas hold each
+// wire's current value (wire_valid / wire_owner) and pull_wires brings a device up to date, device to device, for exactly the
+// rows it is about to read.
+static int32_t pull_wires(tfhe_ctx *c, int dst, const int32_t *wires, int64_t count);
+
 int32_t tfhe_wires_alloc(tfhe_ctx *c, int64_t num_wires)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) {      // one replica of the table per device (multi_gates_level keeps them coherent)
+    ENTER_CTX(c);
+    if (c->multi()) {      // one replica of the table per device
         const int32_t rc = fan_out(c, all_kids(c), [&](int k) { return tfhe_wires_alloc(c->kids[(size_t)k], num_wires); });
-        if (rc == TFHE_OK) { c->num_wires = num_wires; c->wire_stale.assign((size_t)std::max<int64_t>(num_wires, 0), 0); }
+        if (rc == TFHE_OK) {
+            c->num_wires = num_wires;
+            const size_t nw = (size_t)std::max<int64_t>(num_wires, 0);
+            c->wire_valid.assign(c->kids.size(), std::vector<uint8_t>(nw, 1));
+            c->wire_owner.assign(nw, 0);
+        }
         return rc;
     }
     if (num_wires < 0 || num_wires > ((int64_t)1 << 30)) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_alloc: bad wire count");
@@ -1211,7 +1389,8 @@ int32_t tfhe_wires_alloc(tfhe_ctx *c, int64_t num_wires)
 
 static int32_t wires_range_ok(tfhe_ctx *c, const char *who, int64_t first, int64_t count, const void *host)
 {
-    if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "%s: no wire table allocated", who);
+    if (!c->multi() && !c->d_wires) return c->set_err(TFHE_ERR_STATE, "%s: no wire table allocated", who);
+    if (c->multi() && c->num_wires <= 0) return c->set_err(TFHE_ERR_STATE, "%s: no wire table allocated", who);
     if (first < 0 || count < 0 || first + count > c->num_wires || (count > 0 && !host))
         return c->set_err(TFHE_ERR_INVALID_ARG, "%s: wire range [%lld, %lld) outside the table of %lld wires or NULL buffer", who,
                           (long long)first, (long long)(first + count), (long long)c->num_wires);
@@ -1220,10 +1399,14 @@ static int32_t wires_range_ok(tfhe_ctx *c, const char *who, int64_t first, int64
 
 int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32_t *host)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) {
+    ENTER_CTX(c);
+    if (c->multi()) {      // every replica takes the rows: they are valid everywhere afterwards
+        const int32_t rc0 = wires_range_ok(c, "wires_upload", first, count, host);
+        if (rc0 || count == 0) return rc0;
         const int32_t rc = fan_out(c, all_kids(c), [&](int k) { return tfhe_wires_upload(c->kids[(size_t)k], first, count, host); });
-        if (rc == TFHE_OK) std::fill(c->wire_stale.begin() + first, c->wire_stale.begin() + first + count, 0);
+        for (size_t k = 0; k < c->kids.size(); k++)      // (on failure: valid nowhere but where the old value's owner says — mark them all stale except the owner's view is gone too; re-upload is the remedy)
+            std::fill(c->wire_valid[k].begin() + first, c->wire_valid[k].begin() + first + count, rc == TFHE_OK ? 1 : 0);
+        if (rc == TFHE_OK) std::fill(c->wire_owner.begin() + first, c->wire_owner.begin() + first + count, 0);
         return rc;
     }
     int32_t rc = wires_range_ok(c, "wires_upload", first, count, host);
@@ -1237,8 +1420,18 @@ int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32
 
 int32_t tfhe_wires_download(tfhe_ctx *c, int64_t first, int64_t count, int32_t *host)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) { const int32_t rc = tfhe_wires_download(c->kids[0], first, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
+    ENTER_CTX(c);
+    if (c->multi()) {      // the first device is brought up to date for the range, then read
+        int32_t rc = wires_range_ok(c, "wires_download", first, count, host);
+        if (rc || count == 0) return rc;
+        std::vector<int32_t> idx((size_t)count);
+        for (int64_t i = 0; i < count; i++) idx[(size_t)i] = (int32_t)(first + i);
+        rc = pull_wires(c, 0, idx.data(), count);
+        if (rc) return rc;
+        rc = tfhe_wires_download(c->kids[0], first, count, host);
+        if (rc) c->err = c->kids[0]->err;
+        return rc;
+    }
     int32_t rc = wires_range_ok(c, "wires_download", first, count, host);
     if (rc || count == 0) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1251,8 +1444,18 @@ int32_t tfhe_wires_download(tfhe_ctx *c, int64_t first, int64_t count, int32_t *
 
 int32_t tfhe_wires_gather(tfhe_ctx *c, const int32_t *wires, int64_t count, int32_t *host)
 {
-    if (!c) return TFHE_ERR_INVALID_ARG;
-    if (c->multi()) { const int32_t rc = tfhe_wires_gather(c->kids[0], wires, count, host); if (rc) c->err = c->kids[0]->err; return rc; }
+    ENTER_CTX(c);
+    if (c->multi()) {
+        if (c->num_wires <= 0) return c->set_err(TFHE_ERR_STATE, "wires_gather: no wire table allocated");
+        if (count < 0 || (count > 0 && (!wires || !host))) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_gather: NULL argument or negative count");
+        for (int64_t i = 0; i < count; i++)
+            if (wires[i] < 0 || wires[i] >= c->num_wires) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_gather: wire %d outside the table of %lld wires", wires[i], (long long)c->num_wires);
+        int32_t rc = pull_wires(c, 0, wires, count);
+        if (rc) return rc;
+        rc = tfhe_wires_gather(c->kids[0], wires, count, host);
+        if (rc) c->err = c->kids[0]->err;
+        return rc;
+    }
     if (!c->d_wires) return c->set_err(TFHE_ERR_STATE, "wires_gather: no wire table allocated");
     if (count < 0 || (count > 0 && (!wires || !host))) return c->set_err(TFHE_ERR_INVALID_ARG, "wires_gather: NULL argument or negative count");
     if (count == 0) return TFHE_OK;
@@ -1271,27 +1474,6 @@ int32_t tfhe_wires_gather(tfhe_ctx *c, const int32_t *wires, int64_t count, int3
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)count), dim3(256), 0, s, (const int32_t *)c->d_wires, (const int32_t *)c->map.p, (int32_t *)c->io[3].p, n1);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(host, c->io[3].p, (size_t)count * n1 * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    return TFHE_OK;
-}
-
-// rows `host` [count][n+1] -> wires[] of this device's table (the inverse of tfhe_wires_gather; internal)
-static int32_t wires_scatter(tfhe_ctx *c, const int32_t *wires, int64_t count, const int32_t *host)
-{
-    if (count == 0) return TFHE_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
-    const int n1 = c->P.n + 1;
-    int32_t rc = ensure_host_map(c, (size_t)count * 4);
-    if (rc) return rc;
-    memcpy(c->h_map, wires, (size_t)count * 4);
-    HIP_TRY(c, c->map.reserve((size_t)count * 4));
-    HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)count * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, c->io[3].reserve((size_t)count * n1 * 4));
-    HIP_TRY(c, hipMemcpyAsync(c->io[3].p, host, (size_t)count * n1 * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)count), dim3(256), 0, s, (const int32_t *)c->io[3].p, (const int32_t *)c->map.p, c->d_wires, n1);
-    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));
     return TFHE_OK;
 }
@@ -1320,12 +1502,95 @@ static int32_t validate_level(tfhe_ctx *c, int64_t num_wires, const uint8_t *opc
     return TFHE_OK;
 }
 
-// One level on a multi-device context.  Every device holds a replica of the wire table.  A level of fewer than
-// level_split_min blind rotations runs on the first device only (a level costs one blind-rotation latency however few
-// gates it has: spreading a narrow one buys nothing) and its outputs are marked stale on the others; a wide level — the
-// 16 parallel MUXes of examples/tutorial.jl:60 are the small case — first brings the stale wires it reads up to date
-// everywhere, is then cut into rotation-balanced contiguous shards that run concurrently, and finally every device
-// receives the rows the others wrote (host-staged: gather to a host block, scatter from it; no peer access is assumed).
+// Brings device `dst`'s replica up to date for wires[0 .. count): every listed wire whose current value is elsewhere is fetched
+// from its owner — per source device ONE gather on the source's stream, ONE copy, ONE scatter on the destination's stream,
+// ordered by events; nothing is waited for on the host (except a ring slot still in flight from four transfers ago).
+//   peer path  (level_exchange 0 where peer_ok, or 1):  gather -> hipMemcpyPeerAsync on the destination's stream -> scatter
+//   host path  (no peer access, or level_exchange 2):   gather -> D2H into the pair's pinned block on the source's stream
+//                                                       -> H2D on the destination's stream -> scatter
+// Everything runs on the kids' own streams, so it is ordered with the levels before and after it on each device.
+static int32_t pull_wires(tfhe_ctx *c, int dst, const int32_t *wires, int64_t count)
+{
+    const int nk = (int)c->kids.size();
+    std::vector<std::vector<int32_t>> from((size_t)nk);
+    std::vector<uint8_t> &valid = c->wire_valid[(size_t)dst];
+    for (int64_t i = 0; i < count; i++) {
+        const int32_t w = wires[i];
+        if (w < 0 || valid[(size_t)w]) continue;
+        valid[(size_t)w] = 1;                               // (also drops duplicates in the list)
+        from[(size_t)c->wire_owner[(size_t)w]].push_back(w);
+    }
+    tfhe_ctx *kd = c->kids[(size_t)dst];
+    const size_t row = (size_t)(c->P.n + 1) * 4;
+    const int n1 = c->P.n + 1;
+    int32_t rc = TFHE_OK;
+    for (int src = 0; src < nk && rc == TFHE_OK; src++) {
+        const std::vector<int32_t> &rows = from[(size_t)src];
+        if (rows.empty()) continue;
+        tfhe_ctx *ks = c->kids[(size_t)src];
+        auto body = [&]() -> int32_t {
+            PairXfer *&px = c->xfer[(size_t)src * nk + dst];
+            if (!px) px = new PairXfer();
+            PairXfer::Slot &sl = px->slot[px->next++ % PairXfer::kSlots];
+            const size_t cnt = rows.size(), ibytes = cnt * 4, rbytes = cnt * row;
+            const bool peer = c->level_exchange == 1 || (c->level_exchange == 0 && c->peer_ok[(size_t)src * nk + dst]);
+            if (sl.pending) { HIP_TRY(c, hipEventSynchronize(sl.taken)); sl.pending = false; }
+            // source side
+            HIP_TRY(c, hipSetDevice(ks->device));
+            if (!sl.ready) HIP_TRY(c, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+            if (ibytes > sl.h_idx_cap) {
+                if (sl.h_idx) (void)hipHostFree(sl.h_idx);
+                sl.h_idx = nullptr; sl.h_idx_cap = 0;
+                HIP_TRY(c, hipHostMalloc((void **)&sl.h_idx, ibytes * 2 + 256, hipHostMallocPortable));
+                sl.h_idx_cap = ibytes * 2 + 256;
+            }
+            memcpy(sl.h_idx, rows.data(), ibytes);
+            HIP_TRY(c, sl.out.reserve(rbytes));
+            HIP_TRY(c, sl.idx_src.reserve(ibytes));
+            HIP_TRY(c, hipMemcpyAsync(sl.idx_src.p, sl.h_idx, ibytes, hipMemcpyHostToDevice, ks->stream));
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cnt), dim3(256), 0, ks->stream, (const int32_t *)ks->d_wires, (const int32_t *)sl.idx_src.p, (int32_t *)sl.out.p, n1);
+            HIP_TRY(c, hipGetLastError());
+            if (!peer) {
+                if (rbytes > sl.h_rows_cap) {
+                    if (sl.h_rows) (void)hipHostFree(sl.h_rows);
+                    sl.h_rows = nullptr; sl.h_rows_cap = 0;
+                    HIP_TRY(c, hipHostMalloc(&sl.h_rows, rbytes + rbytes / 4 + 256, hipHostMallocPortable));
+                    sl.h_rows_cap = rbytes + rbytes / 4 + 256;
+                }
+                HIP_TRY(c, hipMemcpyAsync(sl.h_rows, sl.out.p, rbytes, hipMemcpyDeviceToHost, ks->stream));
+            }
+            HIP_TRY(c, hipEventRecord(sl.ready, ks->stream));
+            ks->own_pending = true;
+            // destination side
+            HIP_TRY(c, hipSetDevice(kd->device));
+            if (!sl.taken) HIP_TRY(c, hipEventCreateWithFlags(&sl.taken, hipEventDisableTiming));
+            HIP_TRY(c, sl.in.reserve(rbytes));
+            HIP_TRY(c, sl.idx_dst.reserve(ibytes));
+            HIP_TRY(c, hipMemcpyAsync(sl.idx_dst.p, sl.h_idx, ibytes, hipMemcpyHostToDevice, kd->stream));
+            HIP_TRY(c, hipStreamWaitEvent(kd->stream, sl.ready, 0));
+            if (peer) HIP_TRY(c, hipMemcpyPeerAsync(sl.in.p, kd->device, sl.out.p, ks->device, rbytes, kd->stream));
+            else HIP_TRY(c, hipMemcpyAsync(sl.in.p, sl.h_rows, rbytes, hipMemcpyHostToDevice, kd->stream));
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)cnt), dim3(256), 0, kd->stream, (const int32_t *)sl.in.p, (const int32_t *)sl.idx_dst.p, kd->d_wires, n1);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(sl.taken, kd->stream));
+            sl.pending = true;
+            kd->own_pending = true;
+            return TFHE_OK;
+        };
+        rc = body();
+        if (rc)      // what was not fetched is not valid here (the rows of this and the later sources)
+            for (int s2 = src; s2 < nk; s2++)
+                for (int32_t w : from[(size_t)s2]) valid[(size_t)w] = 0;
+    }
+    return rc;
+}
+
+// One level on a multi-device context.  A level of fewer than level_split_min blind rotations runs on the first device only
+// (a level costs one blind-rotation latency however few gates it has: spreading a narrow one buys nothing); a wide level —
+// the 16 parallel MUXes of examples/tutorial.jl:60 are the small case — is cut into rotation-balanced contiguous shards, one
+// per device.  Either way a device first fetches the operand rows whose current value is elsewhere (pull_wires), then runs
+// its gates on its own stream; the outputs are valid on the device that computed them and travel only if somebody else reads
+// them later.  The call returns when everything is queued, exactly as tfhe_gates_level on a one-device context does.
 static int32_t multi_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
                                  const int32_t *out, int64_t B)
 {
@@ -1335,68 +1600,41 @@ static int32_t multi_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int3
     int64_t R = 0;
     for (int64_t g = 0; g < B; g++) R += opcodes[g] == TFHE_GATE_MUX ? 2 : op_has_b(opcodes[g]) ? 1 : 0;
     std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
-    if (nk == 1 || c->level_split_min < 0 || R < c->level_split_min) {
-        rc = tfhe_gates_level(c->kids[0], opcodes, a, b, cc, out, B);
-        if (rc) c->err = c->kids[0]->err;
-        c->kid_ran[0] = 1;
-        if (rc == TFHE_OK && nk > 1) for (int64_t g = 0; g < B; g++) c->wire_stale[(size_t)out[g]] = 1;
-        return rc;
-    }
-    const size_t n1 = (size_t)c->P.n + 1;
-    // 1. stale operands: first device -> host -> the others
-    std::vector<int32_t> need;
-    for (int64_t g = 0; g < B; g++) {
-        const int op = opcodes[g];
-        const int32_t src[3] = {op_has_a(op) ? a[g] : -1, op_has_b(op) ? b[g] : -1, op == TFHE_GATE_MUX ? cc[g] : -1};
-        for (int32_t w : src)
-            if (w >= 0 && c->wire_stale[(size_t)w]) { c->wire_stale[(size_t)w] = 0; need.push_back(w); }
-    }
-    std::vector<int32_t> stage;
-    if (!need.empty()) {
-        stage.resize(need.size() * n1);
-        rc = tfhe_wires_gather(c->kids[0], need.data(), (int64_t)need.size(), stage.data());
-        if (rc) { c->err = c->kids[0]->err; return rc; }
-        std::vector<int> others;
-        for (int k = 1; k < nk; k++) others.push_back(k);
-        rc = fan_out(c, others, [&](int k) { return wires_scatter(c->kids[(size_t)k], need.data(), (int64_t)need.size(), stage.data()); });
-        if (rc) return rc;
-    }
-    // 2. the shards, concurrently
-    std::vector<int64_t> bounds((size_t)nk + 1);
-    shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
-    std::vector<int> which;
-    for (int r = 0; r < nk; r++)
-        if (bounds[(size_t)r + 1] > bounds[(size_t)r]) which.push_back(r);
+    std::vector<int64_t> bounds((size_t)nk + 1, B);
+    bounds[0] = 0;
+    if (!(nk == 1 || c->level_split_min < 0 || R < c->level_split_min)) shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
     auto off = [&](const int32_t *p, int64_t g) { return p ? p + g : nullptr; };
-    rc = fan_out(c, which, [&](int r) {
+    std::vector<int32_t> reads;
+    for (int r = 0; r < nk; r++) {
         const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
-        return tfhe_gates_level(c->kids[(size_t)r], opcodes + s0, off(a, s0), off(b, s0), off(cc, s0), out + s0, cnt);
-    });
-    if (rc) return rc;
-    // 3. all-gather of the written rows through one host block: every shard's device reads its rows out, every device
-    //    takes in what the others wrote (its own shard is the contiguous range [s0, e0) of the block)
-    stage.resize((size_t)B * n1);
-    rc = fan_out(c, which, [&](int r) {
-        const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
-        return tfhe_wires_gather(c->kids[(size_t)r], out + s0, cnt, stage.data() + (size_t)s0 * n1);
-    });
-    if (rc) return rc;
-    rc = fan_out(c, all_kids(c), [&](int k) {
-        const int64_t s0 = bounds[(size_t)k], e0 = bounds[(size_t)k + 1];
-        int32_t r1 = wires_scatter(c->kids[(size_t)k], out, s0, stage.data());
-        if (r1) return r1;
-        return wires_scatter(c->kids[(size_t)k], out + e0, B - e0, stage.data() + (size_t)e0 * n1);
-    });
-    if (rc) return rc;
-    for (int64_t g = 0; g < B; g++) c->wire_stale[(size_t)out[g]] = 0;
-    std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);            // timing / rotation queries describe the shards that computed
-    for (int r : which) c->kid_ran[(size_t)r] = 1;
+        if (cnt <= 0) continue;
+        reads.clear();
+        for (int64_t g = s0; g < s0 + cnt; g++) {
+            const int op = opcodes[g];
+            if (op_has_a(op)) reads.push_back(a[g]);
+            if (op_has_b(op)) reads.push_back(b[g]);
+            if (op == TFHE_GATE_MUX) reads.push_back(cc[g]);
+        }
+        rc = pull_wires(c, r, reads.data(), (int64_t)reads.size());
+        if (rc) return rc;
+        rc = tfhe_gates_level(c->kids[(size_t)r], opcodes + s0, off(a, s0), off(b, s0), off(cc, s0), out + s0, cnt);
+        c->kid_ran[(size_t)r] = 1;
+        // whatever happened to the shard, its output rows on the other devices are no longer current; on failure they are
+        // current nowhere that can be named, which the owner entry records as "device r" all the same: the caller got an error
+        for (int64_t g = s0; g < s0 + cnt; g++) {
+            const size_t w = (size_t)out[g];
+            for (int k = 0; k < nk; k++) c->wire_valid[(size_t)k][w] = (k == r);
+            c->wire_owner[w] = r;
+        }
+        if (rc) return c->set_err(rc, "device %d (kid %d): %s", c->kids[(size_t)r]->device, r, c->kids[(size_t)r]->err.c_str());
+    }
     return TFHE_OK;
 }
 
 int32_t tfhe_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *a, const int32_t *b, const int32_t *cc,
                          const int32_t *out, int64_t B)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_level: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
@@ -1435,6 +1673,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
     t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
+    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec;
     return TFHE_OK;
 }
 
@@ -1461,6 +1700,7 @@ static int32_t multi_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int3
 int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                          const int32_t *in2, int32_t *out, int64_t B)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!opcodes || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
@@ -1483,7 +1723,7 @@ int32_t tfhe_gates_batch(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0
         // ... cut at a ROUND boundary of the one-wave kernel where there is one near the middle: two halves of 4950 rotations
         // are 2.4 rounds each (three launches' worth of partly filled rounds), 4096 + 5804 are 2 + 2.8 — config 3's 8192-gate
         // shard through host buffers: 32.2 ms with the balanced cut, 30.2 ms on one stream (profiles/r04/)
-        if (c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general) {
+        if (c->P.N == kN && c->P.k == 1 && (c->P.bs_l == 2 || c->P.bs_l == 3) && !c->br_general && !c->anyn()) {
             const int64_t resident = 8 * (int64_t)c->cu_count;
             int64_t total = 0;
             for (int64_t g = 0; g < B; g++) total += opcodes[g] == TFHE_GATE_MUX ? 2 : op_has_b(opcodes[g]) ? 1 : 0;
@@ -1558,6 +1798,7 @@ static int32_t gates_batch_one_stream(tfhe_ctx *c, const uint8_t *opcodes, const
 int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                                 const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!ticket) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_submit: NULL ticket");
     *ticket = 2;                                   // "complete": nothing to wait for
@@ -1624,6 +1865,7 @@ int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32
 
 int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (ticket == 2) return TFHE_OK;
     if (ticket != 0 && ticket != 1) return c->set_err(TFHE_ERR_INVALID_ARG, "gates_batch_wait: ticket %d was not issued by tfhe_gates_batch_submit", ticket);
@@ -1647,6 +1889,7 @@ int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket)
 
 int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t *out, int64_t B, int32_t with_keyswitch)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "bootstrap_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
@@ -1700,6 +1943,7 @@ int32_t tfhe_bootstrap_batch(tfhe_ctx *c, int32_t mu, const int32_t *in, int32_t
 
 int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64_t B)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!in || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "keyswitch_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
@@ -1739,30 +1983,60 @@ int32_t tfhe_keyswitch_batch(tfhe_ctx *c, const int32_t *in, int32_t *out, int64
     return TFHE_OK;
 }
 
+// key preparation for whichever kernel family serves this context: Int32 polynomials -> spectra (`scale` folded in), on `s`
+static int32_t launch_bk_prepare(tfhe_ctx *c, const int32_t *d_polys, cplx *d_out, size_t npolys, double scale_if_tuned, bool key_scale, hipStream_t s)
+{
+    if (npolys == 0) return TFHE_OK;
+    if (c->anyn()) {
+        const int log2N = ilog2i(c->P.N), M = c->P.N / 2;
+        const size_t ldsp = (size_t)anyn::padded_len(M > 0 ? M : 1) * sizeof(cplx);
+        if (ldsp > 64 * 1024) LDS_TRY(c, ldsp, anyn::bk_prepare_kernel);
+        hipLaunchKernelGGL(anyn::bk_prepare_kernel, dim3((unsigned)npolys), dim3((unsigned)anyn::threads_for(c->P.N)), ldsp, s, d_polys, d_out,
+                           (const cplx *)c->d_anyn_tab, (const cplx *)(c->d_anyn_tab + M), log2N, key_scale ? 1.0 / (double)M : 1.0);
+    } else {
+        hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, s, d_polys, d_out, c->T, scale_if_tuned);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return TFHE_OK;
+}
+
 static int32_t mk_load_bk_common(tfhe_ctx *c, const void *bk, int32_t parties, bool is_c128)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!bk) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: NULL key pointer");
-    if (parties < 2 || parties > 8 || c->P.parties < parties)
-        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
+    if (parties < 2 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_bootstrap_key: parties must be at least 2 and not exceed the context's max_parties (mk_api.jl:94)");
     if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return mk_load_bk_common(c->kids[(size_t)k], bk, parties, is_c128); });
     HIP_TRY(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->P.N, M = N / 2;
     const size_t per = (size_t)2 * c->P.bs_l * parties + 2 * c->P.bs_l;
     const size_t npolys = (size_t)parties * c->P.n * per;
-    const size_t bytes_in = is_c128 ? npolys * kM * sizeof(cplx) : npolys * kN * 4;
+    const size_t bytes_in = is_c128 ? npolys * M * sizeof(cplx) : npolys * N * 4;
+    quiesce(c);
     if (c->d_mk_bk) { (void)hipFree(c->d_mk_bk); c->d_mk_bk = nullptr; c->have_mk_bk = false; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * kM * sizeof(cplx)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * M * sizeof(cplx)));
     void *d_in = nullptr;
     HIP_TRY(c, hipMalloc(&d_in, bytes_in));
-    hipError_t e = hipMemcpyAsync(d_in, bk, bytes_in, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        if (is_c128) hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_mk_bk);
-        else hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_mk_bk, c->T, 1.0 / kM);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    auto body = [&]() -> int32_t {
+        HIP_TRY(c, hipMemcpyAsync(d_in, bk, bytes_in, hipMemcpyHostToDevice, c->stream));
+        if (is_c128 && c->anyn()) {
+            const size_t total = npolys * M;
+            hipLaunchKernelGGL(anyn::bk_permute_c128_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const cplx *)d_in, c->d_mk_bk, ilog2i(c->P.N) - 1, total);
+            HIP_TRY(c, hipGetLastError());
+        } else if (is_c128) {
+            hipLaunchKernelGGL(bk_permute_c128_kernel, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_mk_bk);
+            HIP_TRY(c, hipGetLastError());
+        } else {
+            const int32_t rcp = launch_bk_prepare(c, (const int32_t *)d_in, c->d_mk_bk, npolys, 1.0 / kM, true, c->stream);
+            if (rcp) return rcp;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return TFHE_OK;
+    };
+    const int32_t rc = body();
     (void)hipFree(d_in);
-    if (e != hipSuccess) return c->set_err(TFHE_ERR_DEVICE, "mk_load_bootstrap_key: %s", hipGetErrorString(e));
+    if (rc) return rc;
     c->mk_parties = parties;
     c->have_mk_bk = true;
     return TFHE_OK;
@@ -1777,10 +2051,11 @@ int32_t tfhe_mk_load_bootstrap_key_c128(tfhe_ctx *c, const double *bk_spectra, i
 int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const int32_t *pub_b, const int32_t *c0, const int32_t *c1,
                                           const int32_t *d0, const int32_t *d1, const int32_t *f0, const int32_t *f1, int32_t *expanded_out)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!pub_b || !c0 || !c1 || !d0 || !d1 || !f0 || !f1) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_expand: NULL argument");
-    if (parties < 2 || parties > 8 || c->P.parties < parties)
-        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_expand: parties must be 2..8 and not exceed the context's max_parties (mk_api.jl:94)");
+    if (parties < 2 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_expand: parties must be at least 2 and not exceed the context's max_parties (mk_api.jl:94)");
     if (c->multi()) {
         // (the expanded key is written to the caller's buffer by the first device only)
         return fan_out(c, all_kids(c), [&](int k) {
@@ -1789,12 +2064,15 @@ int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const in
     }
     HIP_TRY(c, hipSetDevice(c->device));
     const int n = c->P.n, l = c->P.bs_l, P = parties;
+    const size_t N = (size_t)c->P.N, M = N / 2;
+    const bool any = c->anyn();
     const size_t per = (size_t)2 * l * P + 2 * l;
     const size_t npolys = (size_t)P * n * per;
     const size_t nl = (size_t)n * l;                   // polys per party in each of c0 .. f1
     c->have_mk_bk = false;
+    quiesce(c);
     if (c->d_mk_bk) { (void)hipFree(c->d_mk_bk); c->d_mk_bk = nullptr; }
-    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * kM * sizeof(cplx)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_mk_bk, npolys * M * sizeof(cplx)));
     // scratch: the party's 6 uni-encryption arrays, the digit polynomials and their spectra, f0 / f1 spectra, the party's key slice
     int32_t *d_in = nullptr, *d_dec = nullptr, *d_key = nullptr;
     cplx *d_decs = nullptr, *d_fs = nullptr;
@@ -1807,12 +2085,12 @@ int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const in
         if (d_fs) (void)hipFree(d_fs);
     };
     auto body = [&]() -> int32_t {
-        HIP_TRY(c, hipMalloc((void **)&d_in, 6 * nl * kN * 4));
-        HIP_TRY(c, hipMalloc((void **)&d_dec, ndec * kN * 4));
-        HIP_TRY(c, hipMalloc((void **)&d_decs, ndec * kM * sizeof(cplx)));
-        HIP_TRY(c, hipMalloc((void **)&d_fs, 2 * nl * kM * sizeof(cplx)));
-        HIP_TRY(c, hipMalloc((void **)&d_key, (size_t)n * per * kN * 4));
-        std::vector<int32_t> h_dec(ndec * kN);
+        HIP_TRY(c, hipMalloc((void **)&d_in, 6 * nl * N * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_dec, ndec * N * 4));
+        HIP_TRY(c, hipMalloc((void **)&d_decs, ndec * M * sizeof(cplx)));
+        HIP_TRY(c, hipMalloc((void **)&d_fs, 2 * nl * M * sizeof(cplx)));
+        HIP_TRY(c, hipMalloc((void **)&d_key, (size_t)n * per * N * 4));
+        std::vector<int32_t> h_dec(ndec * N);
         hipStream_t s = c->stream;
         for (int i = 0; i < P; i++) {
             // g^-1(b_q[jj] - b_i[jj])[u] for every other party q (tgsw.jl:99-117): [oq][u][jj][N]
@@ -1820,30 +2098,41 @@ int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const in
             for (int q = 0; q < P; q++) {
                 if (q == i) continue;
                 for (int jj = 0; jj < l; jj++) {
-                    const int32_t *bq = pub_b + ((size_t)q * l + jj) * kN, *bi = pub_b + ((size_t)i * l + jj) * kN;
-                    for (int t = 0; t < kN; t++) {
+                    const int32_t *bq = pub_b + ((size_t)q * l + jj) * N, *bi = pub_b + ((size_t)i * l + jj) * N;
+                    for (size_t t = 0; t < N; t++) {
                         const int32_t v = (int32_t)((uint32_t)bq[t] - (uint32_t)bi[t] + (uint32_t)c->g.offset);
-                        for (int u = 0; u < l; u++) h_dec[(((size_t)oq * l + u) * l + jj) * kN + t] = gadget_digit(v, u + 1, c->g);
+                        for (int u = 0; u < l; u++) h_dec[(((size_t)oq * l + u) * l + jj) * N + t] = gadget_digit(v, u + 1, c->g);
                     }
                 }
                 oq++;
             }
             const int32_t *src[6] = {c0, c1, d0, d1, f0, f1};
             for (int a = 0; a < 6; a++)
-                HIP_TRY(c, hipMemcpyAsync(d_in + (size_t)a * nl * kN, src[a] + (size_t)i * nl * kN, nl * kN * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipMemcpyAsync(d_dec, h_dec.data(), ndec * kN * 4, hipMemcpyHostToDevice, s));
-            const int32_t *dc0 = d_in, *dc1 = d_in + nl * kN, *dd0 = d_in + 2 * nl * kN, *dd1 = d_in + 3 * nl * kN, *df = d_in + 4 * nl * kN;
-            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)ndec), dim3(64), 0, s, (const int32_t *)d_dec, d_decs, c->T, 1.0);
-            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)(2 * nl)), dim3(64), 0, s, df, d_fs, c->T, 1.0 / kM);     // f0 then f1
-            MkExpandArgs A;
-            A.dec = d_decs; A.f = d_fs; A.d0 = dd0; A.key = d_key; A.T = c->T; A.n = n; A.l = l; A.parties = P; A.party = i;
-            hipLaunchKernelGGL(mk_expand_kernel, dim3((unsigned)n, (unsigned)(l * (P - 1)), 2), dim3(64), 0, s, A);
-            hipLaunchKernelGGL(mk_expand_copy_kernel, dim3((unsigned)n, (unsigned)l, 4), dim3(256), 0, s, dc0, dc1, dd0, dd1, d_key, n, l, P, i);
-            hipLaunchKernelGGL(bk_prepare_kernel, dim3((unsigned)((size_t)n * per)), dim3(64), 0, s, (const int32_t *)d_key,
-                               c->d_mk_bk + (size_t)i * n * per * kM, c->T, 1.0 / kM);
+                HIP_TRY(c, hipMemcpyAsync(d_in + (size_t)a * nl * N, src[a] + (size_t)i * nl * N, nl * N * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(d_dec, h_dec.data(), ndec * N * 4, hipMemcpyHostToDevice, s));
+            const int32_t *dc0 = d_in, *dc1 = d_in + nl * N, *dd0 = d_in + 2 * nl * N, *dd1 = d_in + 3 * nl * N, *df = d_in + 4 * nl * N;
+            int32_t rcp = launch_bk_prepare(c, (const int32_t *)d_dec, d_decs, ndec, 1.0, false, s);        // multiplier polynomials: unscaled
+            if (rcp) return rcp;
+            rcp = launch_bk_prepare(c, df, d_fs, 2 * nl, 1.0 / kM, true, s);                              // f0 then f1
+            if (rcp) return rcp;
+            if (any) {
+                anyn::MkExpandArgs A;
+                A.dec = d_decs; A.f = d_fs; A.d0 = dd0; A.key = d_key; A.wtab = c->d_anyn_tab; A.twist = c->d_anyn_tab + M;
+                A.n = n; A.l = l; A.parties = P; A.party = i; A.log2N = ilog2i(c->P.N);
+                const size_t ldsp = (size_t)anyn::padded_len(M > 0 ? (int)M : 1) * sizeof(cplx);
+                if (ldsp > 64 * 1024) LDS_TRY(c, ldsp, anyn::mk_expand_kernel);
+                hipLaunchKernelGGL(anyn::mk_expand_kernel, dim3((unsigned)n, (unsigned)(l * (P - 1)), 2), dim3((unsigned)anyn::threads_for(c->P.N)), ldsp, s, A);
+            } else {
+                MkExpandArgs A;
+                A.dec = d_decs; A.f = d_fs; A.d0 = dd0; A.key = d_key; A.T = c->T; A.n = n; A.l = l; A.parties = P; A.party = i;
+                hipLaunchKernelGGL(mk_expand_kernel, dim3((unsigned)n, (unsigned)(l * (P - 1)), 2), dim3(64), 0, s, A);
+            }
+            hipLaunchKernelGGL(mk_expand_copy_kernel, dim3((unsigned)n, (unsigned)l, 4), dim3(256), 0, s, dc0, dc1, dd0, dd1, d_key, n, l, P, i, (int)N);
             HIP_TRY(c, hipGetLastError());
+            rcp = launch_bk_prepare(c, (const int32_t *)d_key, c->d_mk_bk + (size_t)i * n * per * M, (size_t)n * per, 1.0 / kM, true, s);
+            if (rcp) return rcp;
             if (expanded_out)
-                HIP_TRY(c, hipMemcpyAsync(expanded_out + (size_t)i * n * per * kN, d_key, (size_t)n * per * kN * 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipMemcpyAsync(expanded_out + (size_t)i * n * per * N, d_key, (size_t)n * per * N * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));      // h_dec and the scratch buffers are reused by the next party
         }
         return TFHE_OK;
@@ -1858,20 +2147,32 @@ int32_t tfhe_mk_expand_load_bootstrap_key(tfhe_ctx *c, int32_t parties, const in
 
 int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parties)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!ks) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: NULL key pointer");
-    if (parties < 2 || parties > 8 || c->P.parties < parties)
-        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: parties must be 2..8 and not exceed the context's max_parties");
-    if (c->P.ks_log2_base != 2 || c->P.ks_t % 4 != 0 || c->P.N % KS3_SLICES != 0 || c->P.N / KS3_SLICES > 128)
-        return c->set_err(TFHE_ERR_UNSUPPORTED, "mk_load_keyswitch_key: keyswitch base must be 4 and t a multiple of 4");
+    if (parties < 2 || c->P.parties < parties)
+        return c->set_err(TFHE_ERR_INVALID_ARG, "mk_load_keyswitch_key: parties must be at least 2 and not exceed the context's max_parties");
     if (c->multi()) return fan_out(c, all_kids(c), [&](int k) { return tfhe_mk_load_keyswitch_key(c->kids[(size_t)k], ks, parties); });
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n1 = (size_t)c->P.n + 1, stride = (n1 + 3) & ~(size_t)3;
     const size_t rows = (size_t)c->P.N * c->P.ks_t * ((1u << c->P.ks_log2_base) - 1);   // per party (k = 1)
     c->have_mk_ks = false;
+    quiesce(c);
     if (c->d_mk_ksp) { (void)hipFree(c->d_mk_ksp); c->d_mk_ksp = nullptr; }
     if (c->d_mk_ks4) { (void)hipFree(c->d_mk_ks4); c->d_mk_ks4 = nullptr; }
-    const int mode = (c->ks_variant == 4 && c->P.ks_t == 8) ? 4 : 3;
+    if (c->d_ks) { (void)hipFree(c->d_ks); c->d_ks = nullptr; }
+    // the kernel family by keyswitch shape, as for a single key (pick_ks_mode): int8 MFMA for base 4 / t = 8, the tiled integer
+    // kernel for base 4 / t a multiple of 4, the gather kernel for every other base and length (keyswitch.jl:45-80 takes any)
+    const bool ok3 = c->P.ks_log2_base == 2 && c->P.ks_t % 4 == 0 && c->P.N % KS3_SLICES == 0 && c->P.N / KS3_SLICES <= 128;
+    const bool ok4 = c->P.ks_log2_base == 2 && c->P.ks_t == 8 && c->P.N % 128 == 0;
+    const int mode = (c->ks_variant == 4 && ok4) ? 4 : (c->ks_variant >= 3 && ok3) ? 3 : 1;
+    if (mode == 1) {
+        // canonical layout, the parties' keys back to back
+        HIP_TRY(c, hipMalloc((void **)&c->d_ks, (size_t)parties * rows * n1 * 4));
+        HIP_TRY(c, hipMemcpyAsync(c->d_ks, ks, (size_t)parties * rows * n1 * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->mk_ksp_words = rows * n1;
+    } else
     if (mode == 3) {
         // (every copy and kernel of a loader runs on the context's own stream: nothing here depends on what the NULL stream orders)
         HIP_TRY(c, hipMalloc((void **)&c->d_mk_ksp, (size_t)parties * rows * stride * 4));
@@ -1909,6 +2210,7 @@ int32_t tfhe_mk_load_keyswitch_key(tfhe_ctx *c, const int32_t *ks, int32_t parti
 
 int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *in1, int32_t *out, int64_t B)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (B < 0 || (B > 0 && (!in0 || !in1 || !out))) return c->set_err(TFHE_ERR_INVALID_ARG, "mk_gate_nand_batch: NULL argument or negative B");
     if (B == 0) return TFHE_OK;
@@ -1922,7 +2224,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     { const int32_t rc0 = enter_stream(c, s); if (rc0) return rc0; }
-    const int NP = c->mk_parties, n = c->P.n, nw = NP * n + 1, ew = NP * kN + 1;
+    const int NP = c->mk_parties, n = c->P.n, nw = NP * n + 1, Nn = c->P.N /* (1024 in every tuned branch below) */, ew = NP * Nn + 1;
     const size_t bytes = (size_t)B * nw * 4;
     for (int i = 0; i < 2; i++) {
         HIP_TRY(c, c->io[i].reserve(bytes));
@@ -1961,7 +2263,33 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     // 2 parties with l = 4 (mktfhe_parameters_2party, mk_api.jl:4-10): the tuned two-wave kernel; any other shape, and option
     // mk_general, the any-party kernel (round 3's one-wave 2-party kernel is gone: the any-party kernel is the cross-check)
     const bool special = (NP == 2 && c->P.bs_l == 4 && !c->mk_force_general);
-    if (special) {
+    if (c->anyn()) {
+        // any N, any number of parties, any l (kernels_anyn.hpp): one workgroup per rotation, accumulators in global memory
+        const int M = Nn / 2;
+        anyn::Args g;
+        g.diag = a.diag; g.bara = a.bara; g.bk = a.bk; g.ext = a.ext; g.g = c->g; g.n = n; g.mu = a.mu; g.K1 = NP + 1; g.L = c->P.bs_l; g.R = (int32_t)B;
+        g.log2N = ilog2i(Nn); g.parties = NP;
+        g.wtab = c->d_anyn_tab; g.twist = c->d_anyn_tab + M;
+        HIP_TRY(c, c->mk_acc.reserve((size_t)B * (NP + 1) * Nn * sizeof(int32_t)));
+        g.acc = (int32_t *)c->mk_acc.p;
+        const bool fits = anyn::lds_bytes(Nn, 3) <= 160 * 1024;
+        const bool spec_lds = c->anyn_spec < 0 ? fits : (c->anyn_spec == 0 && fits);
+        g.spec_g = nullptr;
+        if (!spec_lds) {
+            HIP_TRY(c, c->spec.reserve((size_t)B * 3 * (M > 0 ? M : 1) * sizeof(cplx)));
+            g.spec_g = (cplx *)c->spec.p;
+        }
+        const size_t ldsa = anyn::lds_bytes(Nn, spec_lds ? 3 : 0);
+        const unsigned nt = (unsigned)anyn::threads_for(Nn);
+        if (dg) {
+            if (ldsa > 64 * 1024) LDS_TRY(c, ldsa, anyn::mk_blind_rotate_kernel<true>);
+            hipLaunchKernelGGL((anyn::mk_blind_rotate_kernel<true>), dim3((unsigned)B), dim3(nt), ldsa, s, g);
+        } else {
+            if (ldsa > 64 * 1024) LDS_TRY(c, ldsa, anyn::mk_blind_rotate_kernel<false>);
+            hipLaunchKernelGGL((anyn::mk_blind_rotate_kernel<false>), dim3((unsigned)B), dim3(nt), ldsa, s, g);
+        }
+        name_kernel(c, spec_lds ? "mk_blind_rotate_kernel_anyn(N=%d,P=%d,l=%d)" : "mk_blind_rotate_kernel_anyn(N=%d,P=%d,l=%d,spec=global)", Nn, NP, c->P.bs_l);
+    } else if (special) {
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
         // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four; DIAG: 1)
         const int rw = dg ? 1 : c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
@@ -1971,7 +2299,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 #define LAUNCH_MK2(LL, DG, RWV)                                                                                    \
         do {                                                                                                       \
             if (lds2 > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_w2<LL, DG, RWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+                LDS_TRY(c, lds2, mk_blind_rotate_kernel_w2<LL, DG, RWV>); \
             hipLaunchKernelGGL((mk_blind_rotate_kernel_w2<LL, DG, RWV>), dim3(nblk), dim3(128 * RWV), lds2, s, a);  \
         } while (0)
         if (dg) LAUNCH_MK2(4, true, 1);
@@ -2035,7 +2363,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 #define LAUNCH_MKG(DG, RWV)                                                                                        \
         do {                                                                                                       \
             if (ldsg > 64 * 1024)                                                                                  \
-                HIP_TRY(c, hipFuncSetAttribute((const void *)mk_blind_rotate_kernel_general<DG, RWV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg)); \
+                LDS_TRY(c, ldsg, mk_blind_rotate_kernel_general<DG, RWV, false>); \
             if (accg) hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, true>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
             else hipLaunchKernelGGL((mk_blind_rotate_kernel_general<DG, RWV, false>), dim3(nblk), dim3(64 * RWV), ldsg, s, ga); \
         } while (0)
@@ -2051,27 +2379,38 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     if (c->ks_mode == 4) {
         Ks4Args a4;
         a4.ext = (const int32_t *)c->ext.p; a4.e0 = d_gate; a4.e1 = nullptr; a4.dst = nullptr; a4.out = (int32_t *)c->io[3].p;
-        a4.n = n; a4.kN = kN; a4.G = (int)B; a4.wtiles = c->ks4_wtiles;
-        a4.in_stride = ew; a4.in_b = NP * kN; a4.out_stride = nw; a4.out_b = NP * n;
+        a4.n = n; a4.kN = Nn; a4.G = (int)B; a4.wtiles = c->ks4_wtiles;
+        a4.in_stride = ew; a4.in_b = NP * Nn; a4.out_stride = nw; a4.out_b = NP * n;
         for (int p = 0; p < NP; p++) {
-            a4.in_off = p * kN; a4.out_off = p * n; a4.add_b = (p == 0); a4.kslices = 1;
+            a4.in_off = p * Nn; a4.out_off = p * n; a4.add_b = (p == 0); a4.kslices = 1;
             a4.Gpad = (int)((B + 63) / 64 * 64);
-            HIP_TRY(c, c->abar.reserve((size_t)(kN / 4) * a4.Gpad * 16));
+            HIP_TRY(c, c->abar.reserve((size_t)(Nn / 4) * a4.Gpad * 16));
             a4.abar_t = (const i32x4 *)c->abar.p;
-            hipLaunchKernelGGL(ks4_digits_kernel, dim3((unsigned)(a4.Gpad / 32), (unsigned)(kN / 128)), dim3(128), 0, s, a4, (i32x4 *)c->abar.p);
+            hipLaunchKernelGGL(ks4_digits_kernel, dim3((unsigned)(a4.Gpad / 32), (unsigned)(Nn / 128)), dim3(128), 0, s, a4, (i32x4 *)c->abar.p);
             a4.bmat = (const i32x4 *)c->d_mk_ks4 + (size_t)p * c->mk_ks4_frags;
             hipLaunchKernelGGL(keyswitch_kernel_v4, dim3((unsigned)((B + 255) / 256), (unsigned)c->ks4_wtiles), dim3(256), 0, s, a4);
+        }
+    } else if (c->ks_mode == 1) {
+        // any base / length: the gather kernel per party, the b words chained through the output (stream-ordered)
+        KsArgs k1;
+        k1.ext = (const int32_t *)c->ext.p; k1.e0 = d_gate; k1.e1 = nullptr; k1.dst = nullptr; k1.out = (int32_t *)c->io[3].p;
+        k1.n = n; k1.kN = c->P.N; k1.t = c->P.ks_t; k1.log2_base = c->P.ks_log2_base;
+        k1.in_stride = ew; k1.in_b = NP * c->P.N; k1.out_stride = nw; k1.out_b = NP * n;
+        for (int p = 0; p < NP; p++) {
+            k1.in_off = p * c->P.N; k1.out_off = p * n; k1.add_b = (p == 0);
+            k1.ks = c->d_ks + (size_t)p * c->mk_ksp_words;
+            hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)B, (unsigned)((n + 1 + 256 * KS1_WPT - 1) / (256 * KS1_WPT))), dim3(256), 0, s, k1);
         }
     } else {
         Ks3Args k3;
         k3.ext = (const int32_t *)c->ext.p; k3.e0 = d_gate; k3.e1 = nullptr; k3.dst = nullptr; k3.out = (int32_t *)c->io[3].p;
-        k3.n = n; k3.kN = kN; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
-        k3.in_stride = ew; k3.in_b = NP * kN; k3.out_stride = nw; k3.out_b = NP * n;
+        k3.n = n; k3.kN = Nn; k3.t = c->P.ks_t; k3.log2_base = 2; k3.stride = c->ks_stride; k3.G = (int)B;
+        k3.in_stride = ew; k3.in_b = NP * Nn; k3.out_stride = nw; k3.out_b = NP * n;
         k3.in_off = 0; k3.out_off = 0; k3.ksp = c->d_mk_ksp;
         hipLaunchKernelGGL(ks3_init_kernel, dim3((unsigned)B), dim3(256), 0, s, k3);
         const unsigned tiles = (unsigned)((B + KS3_G - 1) / KS3_G);
         for (int p = 0; p < NP; p++) {
-            k3.in_off = p * kN; k3.out_off = p * n; k3.ksp = c->d_mk_ksp + (size_t)p * c->mk_ksp_words;
+            k3.in_off = p * Nn; k3.out_off = p * n; k3.ksp = c->d_mk_ksp + (size_t)p * c->mk_ksp_words;
             hipLaunchKernelGGL(keyswitch_kernel_v3, dim3(tiles * KS3_SLICES, (unsigned)((c->ks_stride + 511) / 512)), dim3(128), 0, s, k3);
         }
     }
@@ -2088,6 +2427,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
 
 int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
 {
+    ENTER_CTX(c);
     if (!c || !ms) return TFHE_ERR_INVALID_ARG;
     if (c->multi()) {      // the shards ran concurrently: the batch took as long as the slowest of them
         float worst = -1.f;
@@ -2125,6 +2465,7 @@ int32_t tfhe_last_timing_ms(tfhe_ctx *c, int32_t which, float *ms)
 
 int32_t tfhe_timing_history_ms(tfhe_ctx *c, int32_t which, float *ms, int32_t max_calls, int32_t *n_out)
 {
+    ENTER_CTX(c);
     if (!c || !ms || !n_out || max_calls < 0) return TFHE_ERR_INVALID_ARG;
     *n_out = 0;
     if (c->multi()) return c->set_err(TFHE_ERR_STATE, "timing_history: ask a one-device context (a multi-device context reports the slowest shard per call: tfhe_last_timing_ms)");
@@ -2135,7 +2476,9 @@ int32_t tfhe_timing_history_ms(tfhe_ctx *c, int32_t which, float *ms, int32_t ma
     case 2: a = 0; b = 3; break;
     default: return c->set_err(TFHE_ERR_INVALID_ARG, "timing_history: which must be 0, 1 or 2");
     }
-    const int64_t have = std::min<int64_t>(c->timed_calls, tfhe_ctx::kTimingSlots);
+    // (one slot fewer than the ring holds: the slot the NEXT call records into is the oldest committed set once the ring is full,
+    //  and a call that fails part-way leaves it half overwritten — it is never part of the history)
+    const int64_t have = std::min<int64_t>(c->timed_calls, tfhe_ctx::kTimingSlots - 1);
     const int32_t n = (int32_t)std::min<int64_t>(have, max_calls);
     if (n == 0) return TFHE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2199,9 +2542,12 @@ static int32_t read_diag(tfhe_ctx *c, double *worst, double *mhz)
     if (mhz) {
         std::vector<double> f;
         f.reserve(R);
+        // s_memrealtime ticks at 100 MHz: a workgroup that lived less than 10 us (1000 ticks) gives a ratio with a percent-level
+        // quantisation error and, right after the device woke up, sits on the DVFS ramp — such records are not a clock reading
+        constexpr unsigned long long kMinTicks = 1000;
         for (size_t r = 0; r < R; r++)
-            if (h[R + 2 * r + 1] > 0) f.push_back((double)h[R + 2 * r] / (double)h[R + 2 * r + 1] * 100.0);
-        if (f.empty()) return c->set_err(TFHE_ERR_STATE, "diagnostics: no clock record");
+            if (h[R + 2 * r + 1] >= kMinTicks) f.push_back((double)h[R + 2 * r] / (double)h[R + 2 * r + 1] * 100.0);
+        if (f.empty()) return c->set_err(TFHE_ERR_STATE, "diagnostics: the kernel's workgroups ran for less than 10 us each: too short for a clock reading");
         if (getenv("TFHE_DEBUG_LIFETIMES")) {       // development aid: wave lifetimes from the 100 MHz s_memrealtime counter
             double sum = 0, mn = 1e30, mx = 0;
             for (size_t r = 0; r < R; r++) {
@@ -2231,6 +2577,7 @@ static int32_t read_diag(tfhe_ctx *c, double *worst, double *mhz)
 
 int32_t tfhe_last_rounding_margin(tfhe_ctx *c, double *worst)
 {
+    ENTER_CTX(c);
     if (!c || !worst) return TFHE_ERR_INVALID_ARG;
     if (c->multi()) {
         double m = -1;
@@ -2250,6 +2597,7 @@ int32_t tfhe_last_rounding_margin(tfhe_ctx *c, double *worst)
 
 int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *c, double *mhz)
 {
+    ENTER_CTX(c);
     if (!c || !mhz) return TFHE_ERR_INVALID_ARG;
     if (c->multi()) {
         for (size_t k = 0; k < c->kids.size(); k++) {
@@ -2276,12 +2624,41 @@ int32_t tfhe_debug_phases(tfhe_ctx *c, unsigned long long *out64)
 }
 #endif
 
+// the current value of an option tfhe_set_option takes (so that a caller that changes one for a while can put it back)
+int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value)
+{
+    ENTER_CTX(c);
+    if (!name || !value) return c->set_err(TFHE_ERR_INVALID_ARG, "get_option: NULL argument");
+    if (c->multi() && strcmp(name, "level_split_min") && strcmp(name, "level_exchange")) {
+        const int32_t rc = tfhe_get_option(c->kids[0], name, value);      // set_option gives every device the same value
+        if (rc) c->err = c->kids[0]->err;
+        return rc;
+    }
+    const struct { const char *n; int64_t v; } table[] = {
+        {"br_small", c->br_small}, {"br_tiny", c->br_tiny}, {"br_rt_l", c->br_rt_l}, {"timing_events", c->timing_events},
+        {"br_split", c->br_split}, {"br_general", c->br_general}, {"br_anyn", c->br_anyn}, {"anyn_spec", c->anyn_spec},
+        {"level_split_min", c->level_split_min}, {"level_exchange", c->level_exchange}, {"br_prio_pct", c->br_prio_pct}, {"ks_slices", c->ks_slices_large},
+        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw},
+        {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"mkg_acc", c->mkg_acc},
+        {"mkg_variant", c->mkg_variant}, {"mkg_rw", c->mkg_rw}, {"mk_rw", c->mk_rw}, {"ks_variant", c->ks_variant},
+    };
+    for (const auto &e : table)
+        if (!strcmp(name, e.n)) { *value = e.v; return TFHE_OK; }
+    return c->set_err(TFHE_ERR_INVALID_ARG, "get_option: unknown option '%s'", name);
+}
+
 int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
 {
+    ENTER_CTX(c);
     if (!c) return TFHE_ERR_INVALID_ARG;
     if (!name || !*name) return TFHE_OK;
     if (c->multi()) {
-        if (!strcmp(name, "level_split_min")) { c->level_split_min = value; return TFHE_OK; }       // the one option that belongs to the fan-out context itself
+        if (!strcmp(name, "level_split_min")) { c->level_split_min = value; return TFHE_OK; }       // the options that belong to the fan-out context itself
+        if (!strcmp(name, "level_exchange")) {
+            if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: level_exchange must be 0 (by peer access), 1 (device-to-device) or 2 (host staging)");
+            c->level_exchange = (int)value;
+            return TFHE_OK;
+        }
         for (tfhe_ctx *k : c->kids) {
             const int32_t rc = tfhe_set_option(k, name, value);
             if (rc) { c->err = k->err; return rc; }
@@ -2294,7 +2671,19 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "timing_events")) { c->timing_events = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_split")) { c->br_split = value != 0; return TFHE_OK; }
     if (!strcmp(name, "br_general")) { c->br_general = value != 0; return TFHE_OK; }
-    if (!strcmp(name, "level_split_min")) return TFHE_OK;      // (meaningful on a multi-device context only)
+    if (!strcmp(name, "br_anyn")) {
+        // the any-N kernels read the bootstrapping key in their own spectrum order: choose before loading it
+        if ((c->have_bk || c->have_mk_bk) && (value != 0) != (c->br_anyn != 0))
+            return c->set_err(TFHE_ERR_STATE, "set_option: br_anyn must be chosen before the bootstrapping key is loaded (reload the key after changing it)");
+        c->br_anyn = value != 0;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "anyn_spec")) {
+        if (value < -1 || value > 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: anyn_spec must be -1 (LDS when it fits), 0 (LDS) or 1 (global memory)");
+        c->anyn_spec = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "level_split_min") || !strcmp(name, "level_exchange")) return TFHE_OK;      // (meaningful on a multi-device context only)
     if (!strcmp(name, "br_prio_pct")) {
         if (value < 0 || value > 100) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: br_prio_pct must be 0..100");
         c->br_prio_pct = (int)value;
