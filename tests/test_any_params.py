@@ -172,7 +172,7 @@ def test_lwe_size_1500(tfhe, orc, ks_variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,N,t,gamma", [(700, 1024, 5, 3), (2047, 512, 3, 5), (40, 1024, 15, 2), (33, 64, 4, 1)])
+@pytest.mark.parametrize("n,N,t,gamma", [(700, 1024, 5, 3), (2047, 512, 3, 5), (40, 1024, 15, 2), (33, 64, 16, 1)])
 def test_keyswitch_any_base_any_size(tfhe, orc, n, N, t, gamma):
     """keyswitch.jl:45-80 for a base other than 4 / a length other than 8 / lwe_size up to 2047: the gather kernel, arbitrary
     words against the oracle (and a gate through it)."""
@@ -227,8 +227,8 @@ def _mk_check(tfhe, eng, o, rng, sks, n, expect_kernel, decrypts=True):
 
 MK_ANY = [  # what, parties, N, l, beta, n
     ("2 parties, N = 512", 2, 512, 4, 7, 6),
-    ("3 parties, N = 2048", 3, 2048, 3, 7, 3),
-    ("9 parties (more than the shipped 8)", 9, 1024, 4, 6, 2),
+    ("3 parties, N = 2048", 3, 2048, 4, 7, 3),
+    ("9 parties (more than the shipped 8)", 9, 1024, 8, 4, 2),
     ("2 parties, l = 10 / beta = 3", 2, 1024, 10, 3, 4),
     ("2 parties, N = 64", 2, 64, 4, 5, 5),
 ]

@@ -279,15 +279,17 @@ def test_ragged_batch_mask_size_2(tfhe, orc):
     ops = np.array([tfhe.OPCODES[names[i]] for i in rng.integers(0, len(names), B)], np.uint8)
     ins = [tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, B).astype(bool)).data for _ in range(3)]
     got = eng.gates(ops, *ins)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
+    # (about 2000 rotations = 8 per CU: one full round of seven per CU on the lockstep groups, the rest on the three-wave kernel)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7> + blind_rotate_kernel_k2w3<2>", eng.last_kernel_name()
     idx = sorted({0, 1, 255, 256, 1791, 1792, 1793, B - 1} | set(int(v) for v in rng.choice(B, 40, replace=False)))
     assert np.array_equal(got[idx], K.oracle.gates(ops[idx], *[a[idx] for a in ins], nthreads=16))
     K.ck.close()
 
 
 def test_mask_size_2_round_partition(tfhe, orc):
-    """k = 2, 4096 rotations = 16 per CU: dealt as rounds of 6 + 6 + 4 in two launches (k2_partition, round 4) instead of
-    6 + 5 + 5 in one — same words as the single launch, rows from every segment and the seam equal the oracle."""
+    """k = 2, 4096 rotations = 16 per CU: two rounds of seven per CU on the lockstep groups and the last 512 rotations on the
+    three-waves-per-rotation kernel (k2_partition; round 4 dealt 6 + 6 + 4, all on the one-wave kernel: option k2_w3 = 0) — same
+    words as the single launch, rows from every segment and the seams equal the oracle."""
     from conftest import KeySet
     K = KeySet(tfhe, orc, tfhe.SchemeParameters(16, 1 / 2**15, 1024, 2, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1), seed=778)
     eng = K.ck.engine(0)
@@ -295,9 +297,12 @@ def test_mask_size_2_round_partition(tfhe, orc):
     rng = np.random.default_rng(3)
     x = rng.integers(-2**31, 2**31, size=(R, 17), dtype=np.int64).astype(np.int32)
     got = eng.bootstrap(2**29, x, with_keyswitch=False)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
-    idx = sorted({0, 1, 3071, 3072, 3073, R - 1} | set(int(v) for v in rng.choice(R, 26, replace=False)))
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7> + blind_rotate_kernel_k2w3<2>", eng.last_kernel_name()
+    idx = sorted({0, 1, 3071, 3072, 3073, 3583, 3584, 3585, R - 1} | set(int(v) for v in rng.choice(R, 26, replace=False)))
     assert np.array_equal(got[idx], K.oracle.bootstrap(2**29, x[idx], with_keyswitch=False, nthreads=16))
+    eng.set_option("k2_w3", 0)                # round 4's partition: 6 + 6 + 4 per CU in two launches of the one-wave kernel
+    assert np.array_equal(eng.bootstrap(2**29, x, with_keyswitch=False), got)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
     eng.set_option("br_split", 0)
     assert np.array_equal(eng.bootstrap(2**29, x, with_keyswitch=False), got)
     K.ck.close()

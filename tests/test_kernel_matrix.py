@@ -163,37 +163,51 @@ def test_run_time_l_instantiations_equal_the_templated_ones(tfhe, orc, l):
 
 @pytest.mark.parametrize("l", [2, 3])
 def test_mask_size_2_kernel(tfhe, orc, l):
-    """blind_rotate_kernel_k2<l> (tlwe_mask_size = 2, api.jl:30,55), l = 2 and 3 (the shipped sets with that keyword)."""
+    """tlwe_mask_size = 2 (api.jl:30,55), l = 2 and 3 (the shipped sets with that keyword): blind_rotate_kernel_k2w3<l> (three waves
+    per rotation, wave c owns polynomial c: the default up to two rotations per CU, round 5) and blind_rotate_kernel_k2<l> (one wave
+    per rotation; alone or in lockstep groups of up to seven per workgroup), each with its DIAG instantiation."""
     K = _setup(tfhe, orc, 1024, 2, l, BETA_OTHER[l], n=8)
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(20 + l), 5, K.params.lwe_size + 1)
+    _check(eng, K, x, f"blind_rotate_kernel_k2w3<{l}>", f"k2w3<{l}>")     # the default for a batch this small
+    eng.set_option("k2_w3", 0)
     eng.set_option("k2_rw", 1)                # single-rotation workgroups (and their DIAG instantiation)
     _check(eng, K, x, f"blind_rotate_kernel_k2<{l}>", f"k2<{l}>")
-    # the default: up to seven rotations per workgroup in lockstep, dealt out in equally full rounds of one workgroup per
+    # up to seven rotations per workgroup in lockstep, dealt out in equally full rounds of one workgroup per
     # CU — 5 rotations = five workgroups of one rotation and six idle waves each, then 9
     eng.set_option("k2_rw", 0)
     got = eng.bootstrap(MU, x, with_keyswitch=False)
     assert eng.last_kernel_name() == f"blind_rotate_kernel_k2<{l},rw7>"
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
     x9 = _words(np.random.default_rng(30 + l), 9, K.params.lwe_size + 1)
-    assert np.array_equal(eng.bootstrap(MU, x9, with_keyswitch=False), K.oracle.bootstrap(MU, x9, with_keyswitch=False, nthreads=8))
-    eng.set_option("k2_rw", 0)
+    want9 = K.oracle.bootstrap(MU, x9, with_keyswitch=False, nthreads=8)
+    assert np.array_equal(eng.bootstrap(MU, x9, with_keyswitch=False), want9)
+    eng.set_option("k2_w3", 1)                # the three-wave kernel whatever the batch size
+    assert np.array_equal(eng.bootstrap(MU, x9, with_keyswitch=False), want9)
+    assert eng.last_kernel_name() == f"blind_rotate_kernel_k2w3<{l}>"
+    eng.set_option("k2_w3", -1)
     K.ck.close()
 
 
 def test_mask_size_2_balanced_rounds(tfhe, orc):
-    """The k = 2 dispatcher rule: 1792 + 300 rotations = two equally full rounds on a 256-CU device (workgroups of 5 and 4
-    rotations, the other waves of a group idling at the barriers); rows from the first, the last and the boundary
-    workgroups equal the oracle."""
+    """The k = 2 dispatcher rules on a 256-CU device, 1792 + 300 rotations.  Without the three-wave kernel (k2_w3 = 0): two equally
+    full rounds of the lockstep groups (workgroups of 5 and 4 rotations, the other waves of a group idling at the barriers).  By
+    default (round 5): one full round of seven per CU, the 300 left over on blind_rotate_kernel_k2w3.  Rows from the first, the
+    last and the boundary workgroups equal the oracle either way."""
     K = _setup(tfhe, orc, 1024, 2, 2, BETA_OTHER[2], n=8)
     eng = K.ck.engine(0)
     R = 1792 + 300
     x = np.repeat(_words(np.random.default_rng(77), 4, K.params.lwe_size + 1), (R + 3) // 4, axis=0)[:R].copy()
     x[:, 0] += (np.arange(R, dtype=np.int64) << 20).astype(np.int32)          # distinct first exponents
-    got = eng.bootstrap(MU, x, with_keyswitch=False)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
     idx = [0, 1, 4, 5, 6, 219, 220, 221, 224, 225, 1791, 1792, 1793, 2000, R - 2, R - 1]
-    assert np.array_equal(got[idx], K.oracle.bootstrap(MU, x[idx], with_keyswitch=False, nthreads=8))
+    want = K.oracle.bootstrap(MU, x[idx], with_keyswitch=False, nthreads=8)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7> + blind_rotate_kernel_k2w3<2>", eng.last_kernel_name()
+    assert np.array_equal(got[idx], want)
+    eng.set_option("k2_w3", 0)
+    got0 = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_k2<2,rw7>"
+    assert np.array_equal(got0, got)
     K.ck.close()
 
 

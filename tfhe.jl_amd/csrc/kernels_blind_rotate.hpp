@@ -1518,6 +1518,109 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_k2(BrArgs P)
     if (lane == 0) ext[2 * kN] = acc_lds[2 * kN];
 }
 
+// ---- k = 2, small batches and the last round of a large one: THREE waves per blind rotation (round 5) ------------------
+// blind_rotate_kernel_k2 runs a rotation on one wave: 3 L forward and 3 inverse transforms per CMUX step back to back, and a
+// round of up to four rotations per CU — one wave per SIMD — costs the same 6.8 - 7.3 ms however few rotations it holds
+// (kK2RoundCost, tfhe_engine.hip): a batch of 4096 = 16 per CU pays 7.3 ms for its last four.  Here wave c owns accumulator
+// polynomial c (blind_rotate_kernel_w2's structure with three polynomials): it rotates and decomposes only its own polynomial,
+// runs its L forward transforms, multiplies each spectrum into partial sums of all three output components, keeps its own
+// and hands the other two over — the one for wave c + 1 through its transposition buffer, which changes hands (after the
+// barrier wave c + 1 reads it and keeps it for its inverse transform and the next step's forward transforms: buffer of wave
+// c in step i = (c - i) mod 3), the one for wave c + 2 through a hand-off slot of its own — then adds the two partial sums
+// it receives, inverse-transforms its component and updates its polynomial: L + 1 transforms per wave and step instead of
+// 3 L + 3.  Two barriers per step (the second keeps a slot's reader ahead of its next writer).  64.4 KB of LDS per rotation:
+// two rotations per CU (six waves), so this kernel takes batches of up to two rotations per CU and the last round of a
+// larger one when that is what is left (k2_partition).
+constexpr int kK2W3LdsBytes = 3 * kImg * 4 + (3 * kXchElems + 3 * kM + 64) * (int)sizeof(cplx);      // per rotation
+template <int L, bool MARGIN = false>
+__global__ __launch_bounds__(192, 2) void blind_rotate_kernel_k2w3(BrArgs P)
+{
+    constexpr int K1 = 3;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg]
+    cplx *xch_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);              // [3][kXchElems]: handed round every step
+    cplx *slot_all = xch_all + 3 * kXchElems;                                    // [3][kM]: wave c's partial sum for wave c + 2
+    cplx *tw2_lds = slot_all + 3 * kM;                                           // [8][8]
+    const int wv = wave_in_block();                                              // wave = owned polynomial (scalar)
+    const int lane = (int)threadIdx.x & 63;
+    const int wn1 = wv == 2 ? 0 : wv + 1, wn2 = wv == 0 ? 2 : wv - 1;            // (wv + 1) mod 3, (wv + 2) mod 3
+    int32_t *acc_lds = acc_all + wv * kImg;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int32_t xormask = gadget_xor_mask(L, beta);
+
+    cplx tw1f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
+    if (threadIdx.x < 64) tw2_lds[threadIdx.x] = P.T.tw2[threadIdx.x];
+    if (wv == 2) init_body_poly(lane, bara[P.n] & (2 * kN - 1), P.mu, acc_lds);
+    else init_zero_poly(lane, acc_lds);
+    __syncthreads();
+
+    int a_next = load_uniform_i32(bara) & (2 * kN - 1);
+    int b = wv;                                                                  // this wave's buffer: (wv - i) mod 3
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = a_next;
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
+        // key polys of transform (p, c = wv): [i][p][c][co][8][64]
+        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * kM) + (size_t)wv * K1 * kM + lane;
+        const int bprev = b == 0 ? 2 : b - 1;                                    // buffer of wave wv - 1 in this step
+        cplx *xch = xch_all + b * kXchElems, *xch_next = xch_all + bprev * kXchElems;
+        cplx own[8], o1[8], o2[8];
+        int32_t temp[16];
+        rotate_poly<16>(lane, a, acc_lds, P.g.offset, xormask, temp);
+        auto digit = [&](int p, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            cplx x[8];
+            load_digits2(temp, p + 1, beta, x);
+            const cplx *kp = key + (size_t)p * K1 * K1 * kM;
+            cplx kv[8];
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)wv * kM + k2 * 64];             // co = wv (issued before the FFT)
+            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) own[k2] = FIRST ? cmul(x[k2], kv[k2]) : cfma(x[k2], kv[k2], own[k2]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)wn1 * kM + k2 * 64];            // co = wv + 1
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) o1[k2] = FIRST ? cmul(x[k2], kv[k2]) : cfma(x[k2], kv[k2], o1[k2]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)wn2 * kM + k2 * 64];            // co = wv + 2
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) o2[k2] = FIRST ? cmul(x[k2], kv[k2]) : cfma(x[k2], kv[k2], o2[k2]);
+        };
+        digit(0, std::true_type{});
+#pragma unroll 1
+        for (int p = 1; p < L; p++) digit(p, std::false_type{});
+        // hand the other two components' partial sums over
+        WAVE_LDS_FENCE();
+        cplx *slot = slot_all + wv * kM;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { xch[k2 * 64 + lane] = o1[k2]; slot[k2 * 64 + lane] = o2[k2]; }
+        __syncthreads();
+        const cplx *from2 = slot_all + wn1 * kM;                                 // wave wv + 1's partial sum for wave (wv + 1) + 2 = wv
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) own[k2] = cadd(own[k2], cadd(xch_next[k2 * 64 + lane], from2[k2 * 64 + lane]));
+        WAVE_LDS_FENCE();
+        __syncthreads();                 // every slot has been read: its owner may write it again in the next step
+        fft_inv_wave(lane, own, tw1f, tw2_lds, xch_next);
+        accumulate_poly<MARGIN>(lane, own, acc_lds, &worst);
+        WAVE_LDS_FENCE();
+        b = bprev;
+    }
+    __syncthreads();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    // tlwe_extract_sample (tlwe.jl:55-59): mask polynomials concatenated in order, b = body[0]
+    int32_t *ext = P.ext + w * (2 * kN + 1);
+    if (wv < 2) extract_mask_poly(lane, acc_lds, ext + (size_t)wv * kN);
+    else if (lane == 0) ext[2 * kN] = acc_lds[kMir];
+}
+
 // ---- N = 2048: two waves per blind rotation ----------------------------------------------------------
 // M = 1024 folded points.  One radix-2 DIF stage is split across the two waves of a 128-thread block:
 //   a_j = z_j + z_{j+512}  -> wave 0 -> even frequencies,   b_j = (z_j - z_{j+512}) W_1024^j -> wave 1 -> odd,

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <cmath>
@@ -183,12 +184,22 @@ struct tfhe_ctx {
     std::vector<int32_t> kid_tickets[2];  // multi-device context: per submit slot, the ticket every kid gave for its shard (2: none)
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
+    int k2_w3 = -1;              // tfhe_set_option("k2_w3", -1 | 0 | 1): the three-waves-per-rotation k = 2 kernel for batches of up to two rotations per CU and for the last round of a larger one (-1: by size), never (0), for every batch (1)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
     int64_t pipeline_min = 4096;   // tfhe_set_option("pipeline_min", n); < 0: never
     bool last_call_two_streams = false;   // the last batch call ran as two halves: timings span both streams
-    void *h_map = nullptr; size_t h_map_cap = 0;   // pinned staging for the index maps
-    hipEvent_t map_ev = nullptr; bool map_pending = false;   // guards reuse of h_map
+    // Pinned staging for the index maps of a call, a ring of kMapStages blocks: the H2D copy of a call's maps sits in the stream
+    // behind the previous call's kernels, so with ONE block the host would wait for the previous call to finish before it could
+    // fill in the next one's (a circuit level per call: the host never ran ahead of the device); with four it queues up to three
+    // calls ahead.  ensure_host_map() hands out the next block (h_map / map_ev / map_cur point at it).
+    struct MapStage { void *h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    static constexpr int kMapStages = 4;
+    MapStage map_stage[kMapStages];
+    unsigned map_next = 0;
+    MapStage *map_cur = &map_stage[0];
+    void *h_map = nullptr;                 // = map_cur->h
+    hipEvent_t map_ev = nullptr;           // = map_cur->ev: recorded behind the H2D copy of the block
 
     // "calls on one context must not overlap": the thread inside an entry point owns the context (CallGuard below); a second
     // thread's overlapping call gets TFHE_ERR_STATE instead of racing on the shared workspaces
@@ -401,7 +412,9 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
     for (auto &set : c->evring)
         for (auto &ev : set)
             if ((e = hipEventCreate(&ev)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&c->map_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (auto &st : c->map_stage)
+        if ((e = hipEventCreateWithFlags(&st.ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    c->map_ev = c->map_stage[0].ev;
     if ((e = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     std::vector<cplx> h;
     build_tables(h);
@@ -446,6 +459,22 @@ int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_i
         c->kids.push_back(k);
     }
     c->kid_ran.assign((size_t)n_dev, 0);
+    // Device-to-device copies between the replicas of the wire table (pull_wires): allowed between two kids on the same
+    // device and wherever hipDeviceCanAccessPeer says so; peer access is switched on for those pairs here, once.  Pairs
+    // without it exchange rows through pinned host memory instead.
+    c->peer_ok.assign((size_t)n_dev * n_dev, 0);
+    c->xfer.assign((size_t)n_dev * n_dev, nullptr);
+    for (int a = 0; a < n_dev; a++)
+        for (int b = 0; b < n_dev; b++) {
+            const int da = device_ids[a], db = device_ids[b];
+            if (da == db) { c->peer_ok[(size_t)a * n_dev + b] = 1; continue; }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            if (hipSetDevice(da) != hipSuccess) { (void)hipGetLastError(); continue; }
+            const hipError_t ep = hipDeviceEnablePeerAccess(db, 0);
+            if (ep == hipSuccess || ep == hipErrorPeerAccessAlreadyEnabled) c->peer_ok[(size_t)a * n_dev + b] = 1;
+            (void)hipGetLastError();
+        }
     *out_ctx = c;
     return TFHE_OK;
 }
@@ -456,6 +485,19 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
 {
     if (!c) return;
     if (c->multi()) {
+        for (tfhe_ctx *k : c->kids)        // transfers between the replicas still in flight use the buffers freed below
+            if (k && k->stream) { (void)hipSetDevice(k->device); (void)hipStreamSynchronize(k->stream); }
+        for (PairXfer *x : c->xfer) {
+            if (!x) continue;
+            for (auto &sl : x->slot) {
+                sl.out.release(); sl.idx_src.release(); sl.in.release(); sl.idx_dst.release();
+                if (sl.h_idx) (void)hipHostFree(sl.h_idx);
+                if (sl.h_rows) (void)hipHostFree(sl.h_rows);
+                if (sl.ready) (void)hipEventDestroy(sl.ready);
+                if (sl.taken) (void)hipEventDestroy(sl.taken);
+            }
+            delete x;
+        }
         for (tfhe_ctx *k : c->kids) tfhe_ctx_destroy(k);
         delete c;
         return;
@@ -477,10 +519,12 @@ void tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->d_mk_ksp) (void)hipFree(c->d_mk_ksp);
     c->bara.release(); c->ext.release(); c->map.release(); c->diag.release(); c->abar.release(); c->mk_acc.release(); c->spec.release();
     for (auto &b : c->io) b.release();
-    if (c->h_map) (void)hipHostFree(c->h_map);
+    for (auto &st : c->map_stage) {
+        if (st.h) (void)hipHostFree(st.h);
+        if (st.ev) (void)hipEventDestroy(st.ev);
+    }
     for (auto &set : c->evring)
         for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
-    if (c->map_ev) (void)hipEventDestroy(c->map_ev);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -571,7 +615,8 @@ extern "C" {
 static size_t bk_poly_count(const tfhe_params &p) { return (size_t)p.n * p.bs_l * (p.k + 1) * (p.k + 1); }
 
 // A key source may be a host buffer or (tfhe_keygen_cloud_key) a buffer on THIS context's device.  A buffer on another GPU
-// is refused: copying from it would depend on peer access between the two devices, which this library never enables.
+// is refused: copying from it would depend on peer access between the two devices (a multi-device context enables it only where
+// hipDeviceCanAccessPeer allows, for its wire-table exchange).
 static int32_t check_key_source(tfhe_ctx *c, const void *p, const char *who)
 {
     hipPointerAttribute_t at;
@@ -847,7 +892,7 @@ static void name_kernel(tfhe_ctx *c, const char *fmt, ...)
 
 // Blind rotation of rotations [first, first + R) of the batch (rows of the bara / ext workspaces): picks the kernel for a
 // batch of R rotations, launches it on `s` and names it.
-static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int32_t mu, hipStream_t s, const DiagArgs &diag)
+static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int32_t mu, hipStream_t s, const DiagArgs &diag, int k2_kind = -1 /* k = 2: 0 = one wave per rotation, 1 = three, -1 = by batch size */)
 {
     BrArgs a;
     a.diag = diag;
@@ -956,6 +1001,22 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         //  slots free up — no rounds, six rotations per CU: 1792 rotations 15.8 vs 11.4 ms, 4096: 30.8 vs 29.9, 7168: 49.9 vs 43.5,
         //  16384: 105.5 vs 100.1; profiles/r04/r04b_k2.jsonl)
         const size_t cus = (size_t)c->cu_count;
+        // three waves per rotation (blind_rotate_kernel_k2w3: wave c owns polynomial c): up to two rotations per CU, where the
+        // one-wave kernel would keep one SIMD in four busy — and the last round of a larger batch (k2_partition)
+        const bool w3 = k2_kind >= 0 ? k2_kind == 1 : (c->k2_w3 == 1 || (c->k2_w3 < 0 && R <= 2 * cus));
+        if (w3) {
+            const size_t ldsw = kK2W3LdsBytes;
+#define LAUNCH_K2W3(LL)                                                                                            \
+            do {                                                                                                   \
+                if (dg) { LDS_TRY(c, ldsw, blind_rotate_kernel_k2w3<LL, true>); hipLaunchKernelGGL((blind_rotate_kernel_k2w3<LL, true>), dim3((unsigned)R), dim3(192), ldsw, s, a); } \
+                else { LDS_TRY(c, ldsw, blind_rotate_kernel_k2w3<LL, false>); hipLaunchKernelGGL((blind_rotate_kernel_k2w3<LL, false>), dim3((unsigned)R), dim3(192), ldsw, s, a); } \
+            } while (0)
+            BR_CASES(LAUNCH_K2W3)
+#undef LAUNCH_K2W3
+            HIP_TRY(c, hipGetLastError());
+            name_kernel(c, "blind_rotate_kernel_k2w3<%d>", L);
+            return TFHE_OK;
+        }
         const bool grouped = !dg && (c->k2_rw == 7 || c->k2_rw == 0);     // (never slower than single-rotation workgroups: 6.7 vs 6.9 ms at 64 rotations, 6.8 vs 7.6 at 512)
         if (grouped) {
             const size_t rounds = (R + 7 * cus - 1) / (7 * cus);
@@ -1069,31 +1130,45 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
 // this table against 6 + 5 + 5 -> 28.4).  k2_partition() picks the round sizes by dynamic programming over that table; rounds
 // of (nearly) equal size share a launch (the kernel deals a launch's rotations out in equally full rounds itself).
 static const double kK2RoundCost[8] = {0.0, 6.8, 6.85, 7.2, 7.3, 9.45, 9.55, 10.3};
-static std::vector<size_t> k2_partition(size_t R, size_t cus)
+// ... and a LAST round of one or two rotations per CU on the three-waves-per-rotation kernel (blind_rotate_kernel_k2w3): 3.1 ms up
+// to one rotation per CU (three waves on three SIMDs), 4.3 ms up to two (six waves on four SIMDs) — against 6.8 on the one-wave
+// kernel (profiles/r05/r05f_k2_sweep.jsonl).  Same device, tlwe_parameters_80(tlwe_mask_size = 2): a single gate 3.11 vs 6.78 ms,
+// 512 rotations 4.32 vs 6.84, 2048: 13.7 vs 14.5, 2304: 14.5 vs 16.8, 4096: 26.8 vs 27.3 (rounds of 7 + 7 per CU and 512
+// rotations on the three-wave kernel instead of 6 + 6 + 4: the table says 24.9 — back-to-back launches cost 1 - 2 ms it does not know).
+static double kK2W3RoundCost[3] = {0.0, 3.1, 4.3};
+struct K2Seg { size_t count; int kind; };       // kind: 0 = blind_rotate_kernel_k2 (lockstep groups), 1 = blind_rotate_kernel_k2w3
+static std::vector<K2Seg> k2_partition(size_t R, size_t cus, bool allow_w3)
 {
     const size_t q = (R + cus - 1) / cus;                    // rotations per CU, rounded up
-    if (q <= 7) return {R};
+    if (q <= 2 && allow_w3) return {{R, 1}};
+    if (q <= 7 && !allow_w3) return {{R, 0}};
     std::vector<double> best(q + 1, 1e300);
     std::vector<int> take(q + 1, 0);
     best[0] = 0.0;
     for (size_t i = 1; i <= q; i++)
         for (int n = 1; n <= 7 && (size_t)n <= i; n++)
             if (best[i - n] + kK2RoundCost[n] < best[i]) { best[i] = best[i - n] + kK2RoundCost[n]; take[i] = n; }
+    // the tail: nothing, or t = 1 / 2 rotations per CU on the three-wave kernel
+    int tail = 0;
+    double total = best[q];
+    for (int t = 1; allow_w3 && t <= 2 && (size_t)t <= q; t++)
+        if (best[q - t] + kK2W3RoundCost[t] < total) { total = best[q - t] + kK2W3RoundCost[t]; tail = t; }
     std::vector<int> rounds;
-    for (size_t i = q; i > 0; i -= (size_t)take[i]) rounds.push_back(take[i]);
+    for (size_t i = q - (size_t)tail; i > 0; i -= (size_t)take[i]) rounds.push_back(take[i]);
     std::sort(rounds.begin(), rounds.end(), std::greater<int>());
     // consecutive rounds of the same size -> one launch; the last launch takes what is left of R
-    std::vector<size_t> seg;
+    std::vector<K2Seg> seg;
     size_t done = 0;
-    for (size_t i = 0; i < rounds.size();) {
+    for (size_t i = 0; i < rounds.size() && done < R;) {
         size_t j = i;
         while (j < rounds.size() && rounds[j] == rounds[i]) j++;
-        size_t want = (size_t)rounds[i] * (j - i) * cus;
-        if (j == rounds.size() || done + want >= R) { seg.push_back(R - done); done = R; break; }
-        seg.push_back(want);
+        const size_t want = (size_t)rounds[i] * (j - i) * cus;
+        if ((j == rounds.size() && !tail) || done + want >= R) { seg.push_back({R - done, 0}); done = R; break; }
+        seg.push_back({want, 0});
         done += want;
         i = j;
     }
+    if (done < R) seg.push_back({R - done, 1});
     return seg;
 }
 
@@ -1102,25 +1177,26 @@ static int32_t launch_blind_rotate(tfhe_ctx *c, size_t R, int32_t mu, hipStream_
     DiagArgs diag;
     int32_t rc = prepare_diag(c, R, s, diag);
     if (rc) return rc;
-    std::vector<size_t> seg;                                   // rotations per launch, in order
+    std::vector<K2Seg> seg;                                    // rotations per launch (and, k = 2, which kernel), in order
     const bool tuned_l = c->P.bs_l == 2 || c->P.bs_l == 3;
     if (c->anyn()) {
         // one launch
-    } else if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7)) {
-        seg = k2_partition(R, (size_t)c->cu_count);
+    } else if (c->br_split && !c->br_general && !c->measure_margin && c->P.N == kN && c->P.k == 2 && tuned_l && (c->k2_rw == 0 || c->k2_rw == 7) && c->k2_w3 != 1) {
+        seg = k2_partition(R, (size_t)c->cu_count, c->k2_w3 < 0);
     } else if (c->br_split && !c->br_general && c->P.N == kN && c->P.k == 1 && c->br_small > 0) {      // (any l: the run-time-l instantiations)
         const size_t resident = 8 * (size_t)c->cu_count;      // rotations of blind_rotate_kernel_v3 on the chip
-        if (R > resident && R % resident > 0 && R % resident <= (size_t)c->br_small) seg = {R - R % resident, R % resident};
+        if (R > resident && R % resident > 0 && R % resident <= (size_t)c->br_small) seg = {{R - R % resident, -1}, {R % resident, -1}};
     }
-    if (seg.size() <= 1) return launch_blind_rotate_part(c, 0, R, mu, s, diag);
+    if (seg.empty()) return launch_blind_rotate_part(c, 0, R, mu, s, diag);
+    if (seg.size() == 1) return launch_blind_rotate_part(c, 0, R, mu, s, diag, seg[0].kind);
     std::string names;
     size_t first = 0;
-    for (size_t n : seg) {
-        rc = launch_blind_rotate_part(c, first, n, mu, s, diag);
+    for (const K2Seg &sg : seg) {
+        rc = launch_blind_rotate_part(c, first, sg.count, mu, s, diag, sg.kind);
         if (rc) return rc;
         if (names.empty() || names.substr(names.rfind(" + ") == std::string::npos ? 0 : names.rfind(" + ") + 3) != c->last_kernel)
             names += (names.empty() ? "" : " + ") + c->last_kernel;
-        first += n;
+        first += sg.count;
     }
     c->last_kernel = names;
     return TFHE_OK;
@@ -1225,15 +1301,20 @@ static void commit_timing_slot(tfhe_ctx *c)
 
 static int32_t ensure_host_map(tfhe_ctx *c, size_t bytes)
 {
-    if (c->map_pending) {   // the previous call's H2D copy of the staging block must have been consumed
-        HIP_TRY(c, hipEventSynchronize(c->map_ev));
-        c->map_pending = false;
+    tfhe_ctx::MapStage &st = c->map_stage[c->map_next++ % tfhe_ctx::kMapStages];
+    if (st.pending) {   // the H2D copy of the call that used this block (four calls ago) must have been consumed
+        HIP_TRY(c, hipEventSynchronize(st.ev));
+        st.pending = false;
     }
-    if (bytes <= c->h_map_cap) return TFHE_OK;
-    if (c->h_map) (void)hipHostFree(c->h_map);
-    c->h_map = nullptr; c->h_map_cap = 0;
-    HIP_TRY(c, hipHostMalloc(&c->h_map, bytes + bytes / 4 + 256, hipHostMallocDefault));
-    c->h_map_cap = bytes + bytes / 4 + 256;
+    if (bytes > st.cap) {
+        if (st.h) (void)hipHostFree(st.h);
+        st.h = nullptr; st.cap = 0;
+        HIP_TRY(c, hipHostMalloc(&st.h, bytes + bytes / 4 + 256, hipHostMallocDefault));
+        st.cap = bytes + bytes / 4 + 256;
+    }
+    c->map_cur = &st;
+    c->h_map = st.h;
+    c->map_ev = st.ev;
     return TFHE_OK;
 }
 
@@ -1247,6 +1328,10 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
                          const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, const int32_t *ia, const int32_t *ib,
                          const int32_t *ic, const int32_t *io, hipStream_t s)
 {
+    static const bool dbg_host = getenv("TFHE_DEBUG_HOSTTIME") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto MARK = [&](int k) { if (dbg_host) { const auto t = std::chrono::steady_clock::now(); t_acc[k] += std::chrono::duration<double, std::micro>(t - t_prev).count(); t_prev = t; } };
     // classify gates: rotations (R), keyswitches (G), trivial (T)
     size_t R = 0, G = 0, Tn = 0;
     bool need1 = false, need2 = false, need0 = false;
@@ -1269,8 +1354,10 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     // index maps, one pinned staging block:
     //   rot_a[R] | rot_b[R] | ks_e0[G] | ks_e1[G] | ks_dst[G] | triv_src[T] | triv_dst[T] | rot_kind[R] | triv_op[T]
     const size_t map_bytes = (2 * R + 3 * G + 2 * Tn) * 4 + R + Tn;
+    MARK(0);
     int32_t rc = ensure_host_map(c, map_bytes);
     if (rc) return rc;
+    MARK(1);
     int32_t *h_ra = (int32_t *)c->h_map, *h_rb = h_ra + R;
     int32_t *h_e0 = h_rb + R, *h_e1 = h_e0 + G, *h_dst = h_e1 + G, *h_ts = h_dst + G, *h_td = h_ts + Tn;
     uint8_t *h_kind = (uint8_t *)(h_td + Tn), *h_top = h_kind + R;
@@ -1296,10 +1383,13 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
             }
         }
     }
+    MARK(2);
     HIP_TRY(c, c->map.reserve(map_bytes));
     HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, map_bytes, hipMemcpyHostToDevice, s));
+    MARK(3);
     HIP_TRY(c, hipEventRecord(c->map_ev, s));
-    c->map_pending = true;
+    MARK(4);
+    c->map_cur->pending = true;
     const int32_t *d_ra = (const int32_t *)c->map.p, *d_rb = d_ra + R;
     const int32_t *d_e0 = d_rb + R, *d_e1 = d_e0 + G, *d_dst = d_e1 + G, *d_ts = d_dst + G, *d_td = d_ts + Tn;
     const uint8_t *d_kind = (const uint8_t *)(d_td + Tn), *d_top = d_kind + R;
@@ -1315,6 +1405,7 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
                            (int32_t *)c->bara.p, n, ilog2i(2 * c->P.N));
         HIP_TRY(c, hipGetLastError());
     }
+    MARK(5);
     if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[1], s));
     if (R > 0) {
         rc = launch_blind_rotate(c, R, (int32_t)(1u << 29), s);   // mu = encode_message(1, 8), gates.jl:17
@@ -1322,6 +1413,7 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     } else {
         c->diag_rows = 0;
     }
+    MARK(6);
     if (!no_ev) HIP_TRY(c, hipEventRecord(c->ev[2], s));
     if (G > 0) {
         rc = launch_keyswitch(c, G, d_e0, d_e1, d_dst, (const int32_t *)c->ext.p, d_out, s);
@@ -1334,6 +1426,9 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
     }
     if (!no_ev) commit_timing_slot(c);
     c->last_rotations = (int64_t)R;
+    MARK(7);
+    if (dbg_host) fprintf(stderr, "run_gates host us: classify+enter %.0f | stage %.0f | fill %.0f | map H2D %.0f | map event %.0f | prologue %.0f | blind rotate %.0f | keyswitch+trivial %.0f\n",
+                          t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4], t_acc[5], t_acc[6], t_acc[7]);
     return leave_stream(c, s);
 }
 
@@ -1604,6 +1699,9 @@ static int32_t multi_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int3
     bounds[0] = 0;
     if (!(nk == 1 || c->level_split_min < 0 || R < c->level_split_min)) shard_bounds_by_rotations(opcodes, B, nk, bounds.data());
     auto off = [&](const int32_t *p, int64_t g) { return p ? p + g : nullptr; };
+    // Phase 1: every shard's device fetches the operand rows it lacks.  All transfers are queued BEFORE any shard's gates: a
+    // gather sits in its source device's stream, and queued behind that device's own shard of THIS level it would make the
+    // reader wait for a level it does not depend on (a level reads only what earlier levels wrote).
     std::vector<int32_t> reads;
     for (int r = 0; r < nk; r++) {
         const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
@@ -1617,10 +1715,14 @@ static int32_t multi_gates_level(tfhe_ctx *c, const uint8_t *opcodes, const int3
         }
         rc = pull_wires(c, r, reads.data(), (int64_t)reads.size());
         if (rc) return rc;
+    }
+    // Phase 2: the shards, each on its device's stream
+    for (int r = 0; r < nk; r++) {
+        const int64_t s0 = bounds[(size_t)r], cnt = bounds[(size_t)r + 1] - s0;
+        if (cnt <= 0) continue;
         rc = tfhe_gates_level(c->kids[(size_t)r], opcodes + s0, off(a, s0), off(b, s0), off(cc, s0), out + s0, cnt);
         c->kid_ran[(size_t)r] = 1;
-        // whatever happened to the shard, its output rows on the other devices are no longer current; on failure they are
-        // current nowhere that can be named, which the owner entry records as "device r" all the same: the caller got an error
+        // the shard's output rows are current on device r only (on failure nowhere that can be named; the caller got the error)
         for (int64_t g = s0; g < s0 + cnt; g++) {
             const size_t w = (size_t)out[g];
             for (int k = 0; k < nk; k++) c->wire_valid[(size_t)k][w] = (k == r);
@@ -1673,7 +1775,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
     t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
-    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec;
+    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3;
     return TFHE_OK;
 }
 
@@ -2242,7 +2344,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
     HIP_TRY(c, c->map.reserve((size_t)B * 5));
     HIP_TRY(c, hipMemcpyAsync(c->map.p, c->h_map, (size_t)B * 5, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipEventRecord(c->map_ev, s));
-    c->map_pending = true;
+    c->map_cur->pending = true;
     const int32_t *d_gate = (const int32_t *)c->map.p;
     const uint8_t *d_kind = (const uint8_t *)(d_gate + B);
     next_timing_slot(c);
@@ -2638,7 +2740,7 @@ int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value)
         {"br_small", c->br_small}, {"br_tiny", c->br_tiny}, {"br_rt_l", c->br_rt_l}, {"timing_events", c->timing_events},
         {"br_split", c->br_split}, {"br_general", c->br_general}, {"br_anyn", c->br_anyn}, {"anyn_spec", c->anyn_spec},
         {"level_split_min", c->level_split_min}, {"level_exchange", c->level_exchange}, {"br_prio_pct", c->br_prio_pct}, {"ks_slices", c->ks_slices_large},
-        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw},
+        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3},
         {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"mkg_acc", c->mkg_acc},
         {"mkg_variant", c->mkg_variant}, {"mkg_rw", c->mkg_rw}, {"mk_rw", c->mk_rw}, {"ks_variant", c->ks_variant},
     };
@@ -2699,6 +2801,16 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "w2_rw")) {
         if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: w2_rw must be 0 (by batch size), 1 or 2");
         c->w2_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "k2_w3")) {
+        if (value < -1 || value > 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_w3 must be -1 (by batch size), 0 (never) or 1 (always)");
+        c->k2_w3 = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "k2_w3_cost_us")) {      // measurement aid: the round cost the partition prices the three-wave tail at (microseconds)
+        if (value < 0) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: k2_w3_cost_us must be >= 0");
+        kK2W3RoundCost[1] = (double)value / 1000.0; kK2W3RoundCost[2] = (double)value / 1000.0 + 0.1;
         return TFHE_OK;
     }
     if (!strcmp(name, "k2_rw")) {

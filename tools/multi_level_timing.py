@@ -69,10 +69,16 @@ for label, dv in (("one_device", devs[0]), ("multi", devs)):
         return host, final
 
     run(20)                                    # warm-up: kernels loaded, buffers sized, clocks up
+    # from an idle device: how long the host is held by the first three levels of a burst (the call returns when a level is
+    # queued; in the steady state below the host runs up to three levels ahead of the device and is then paced by it)
+    t0 = time.perf_counter()
+    burst_host, _ = run(3)
+    burst_wall = time.perf_counter() - t0
     t0 = time.perf_counter()
     host, final = run(a.levels)
     wall = time.perf_counter() - t0
-    res[label] = {"host_us_per_level_inside_gates_level": round(host / a.levels * 1e6, 1),
+    res[label] = {"burst_of_3_levels_host_us_inside_gates_level": round(burst_host * 1e6, 1), "burst_of_3_levels_wall_us": round(burst_wall * 1e6, 1),
+                  "host_us_per_level_inside_gates_level": round(host / a.levels * 1e6, 1),
                   "wall_us_per_level": round(wall / a.levels * 1e6, 1),
                   "devices_in_last_level": eng.last_device_count() if hasattr(eng, "last_device_count") else None,
                   "final_checksum": int(np.bitwise_xor.reduce(final.view(np.uint32).reshape(-1)))}
