@@ -8,6 +8,10 @@
 # writes  ref_gates80.tfhe   13 gate kinds x all input combinations, tfhe_parameters_80, seed 123 (test/runtests.jl:26-40)
 #         ref_gates128.tfhe  NAND / MUX truth tables, tfhe_parameters_128                     (test/runtests.jl:43-57)
 #         ref_mk2.tfhe       2-party multi-key NAND x 10                                       (test/runtests.jl:60-100)
+#         ref_gates_n512.tfhe, ref_gates_n4096.tfhe   NAND / XOR / MUX truth tables on sets the reference ships no constructor for
+#                            but accepts (SchemeParameters is a positional struct, src/api.jl:4-21): N = 512 with
+#                            tfhe_parameters_80's other fields, N = 4096 with tfhe_parameters_128's — the engine's any-N kernels
+#         ref_mk2_n512.tfhe  2-party multi-key NAND x 10 at N = 512
 # By default the LWE dimension is cut to 16 (every other parameter as shipped) so that a file is 1-5 MB and can be
 # committed; pass lwe_size = 0 for the full-size sets (82 / 100 / 300 MB).  The blind rotation then has 16 steps instead
 # of 500 / 630: the same code path, a shorter loop.
@@ -122,3 +126,12 @@ mint_single(joinpath(outdir, "ref_gates80.tfhe"), with_lwe_size(tfhe_parameters_
             [NAND, OR, AND, XOR, XNOR, NOT, NOR, ANDNY, ANDYN, ORNY, ORYN, MUX, CONST0, CONST1])
 mint_single(joinpath(outdir, "ref_gates128.tfhe"), with_lwe_size(tfhe_parameters_128(), lwe_size), [NAND, MUX])
 mint_mk(joinpath(outdir, "ref_mk2.tfhe"), with_lwe_size(mktfhe_parameters_2party, lwe_size), 2)
+
+# parameter sets outside the shipped polynomial degree (round 5: the engine accepts every power-of-two N; these pin its any-N
+# kernels — csrc/kernels_anyn.hpp — against the reference too)
+with_degree(p, N) = TFHE.SchemeParameters(
+    p.lwe_size, p.lwe_noise_stddev, N, p.tlwe_mask_size, p.bs_decomp_length, p.bs_log2_base,
+    p.bs_noise_stddev, p.ks_decomp_length, p.ks_log2_base, p.ks_noise_stddev, p.max_parties)
+mint_single(joinpath(outdir, "ref_gates_n512.tfhe"), with_degree(with_lwe_size(tfhe_parameters_80(), lwe_size), 512), [NAND, XOR, MUX])
+mint_single(joinpath(outdir, "ref_gates_n4096.tfhe"), with_degree(with_lwe_size(tfhe_parameters_128(), lwe_size), 4096), [NAND, XOR, MUX])
+mint_mk(joinpath(outdir, "ref_mk2_n512.tfhe"), with_degree(with_lwe_size(mktfhe_parameters_2party, lwe_size), 512), 2)

@@ -381,3 +381,37 @@ def test_timing_history_never_reports_the_slot_being_recorded(tfhe, keys80):
     h = eng.timing_history_ms(2)
     assert len(h) == 32 and all(0.0 < v < 1000.0 for v in h), h
     eng.close()
+
+
+@pytest.mark.gpu
+def test_n512_full_size_set(tfhe, orc):
+    """A full-size set on the any-N kernel: tfhe_parameters_80 with N = 512 (500 CMUX steps, keyswitch from 512 words on the MFMA
+    kernel), 1200 mixed gates: every output decrypts, 96 sampled rows equal the oracle word for word, the DIAG run gives the same
+    words with a margin below 0.25."""
+    from conftest import KeySet
+    b = tfhe.tfhe_parameters_80()
+    p = tfhe.SchemeParameters(b.lwe_size, b.lwe_noise_stddev, 512, 1, b.bs_decomp_length, b.bs_log2_base, b.bs_noise_stddev,
+                              b.ks_decomp_length, b.ks_log2_base, b.ks_noise_stddev, 1)
+    K = KeySet(tfhe, orc, p, seed=512)
+    eng = K.ck.engine(0)
+    rng = np.random.default_rng(512)
+    B = 1200
+    names = ["NAND", "AND", "OR", "XOR", "MUX"]
+    sel = rng.integers(0, 5, B)
+    ops = np.array([tfhe.OPCODES[nm] for nm in names], np.uint8)[sel]
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ins = [tfhe.encrypt(K.rng, K.sk, v).data for v in bits]
+    got = eng.gates(ops, *ins)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_anyn(N=512,k=1,l=2)"
+    x, y, z = bits
+    want = np.select([sel == 0, sel == 1, sel == 2, sel == 3, sel == 4], [~(x & y), x & y, x | y, x ^ y, np.where(x, y, z)])
+    assert np.array_equal(tfhe.decrypt(K.sk, got), want)
+    idx = rng.choice(B, 96, replace=False)
+    assert np.array_equal(got[idx], K.oracle.gates(ops[idx], *[a[idx] for a in ins], nthreads=orc.max_threads()))
+    eng.set_option("measure_margin", 1)
+    again = eng.gates(ops[:64], *[a[:64] for a in ins])
+    margin = eng.last_rounding_margin()
+    eng.set_option("measure_margin", 0)
+    assert np.array_equal(again, got[:64]) and 0.0 < margin < 0.25, margin
+    print(f"  rounding margin, tfhe_parameters_80 with N = 512, full size: {margin:.4f}")
+    K.ck.close()

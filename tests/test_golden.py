@@ -141,17 +141,18 @@ def test_gpu_reproduces_reference_fixtures(tfhe, orc):
         check_reference_fixture(read_sections(f), tfhe, orc, gpu=True)
 
 
-def _mint_twin(tfhe, orc, path, multikey):
-    """Python twin of julia/TFHEMI355X/scripts/mint_fixtures.jl (same container and section names), data from this repo's keygen + oracle."""
+def _mint_twin(tfhe, orc, path, multikey, N=1024):
+    """Python twin of julia/TFHEMI355X/scripts/mint_fixtures.jl (same container and section names), data from this repo's keygen + oracle.
+    N = 512: the twin of ref_gates_n512.tfhe / ref_mk2_n512.tfhe (a set the engine runs on its any-N kernels)."""
     from tfhe_jl_amd.serialize import write_sections
     rng = np.random.default_rng(5)
     if multikey:
         b = tfhe.mktfhe_parameters_2party
-        p = tfhe.SchemeParameters(8, b.lwe_noise_stddev, 1024, 1, 4, 7, b.bs_noise_stddev, 8, 2, b.ks_noise_stddev, 2)
+        p = tfhe.SchemeParameters(8, b.lwe_noise_stddev, N, 1, 4, 7, b.bs_noise_stddev, 8, 2, b.ks_noise_stddev, 2)
         sks = [tfhe.SecretKey(rng, p) for _ in range(2)]
         shared = tfhe.SharedKey(rng, p)
         ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, s, shared) for s in sks])
-        o = orc.Oracle(8, 1024, 1, 4, 7, 8, 2, parties=2)
+        o = orc.Oracle(8, N, 1, 4, 7, 8, 2, parties=2)
         o.load_bootstrap_key(ck.bootstrap_key)
         o.load_keyswitch_key(ck.keyswitch_key)
         bits = rng.integers(0, 2, (2, 6)).astype(bool)
@@ -163,9 +164,9 @@ def _mint_twin(tfhe, orc, path, multikey):
             "lwe_keys": np.stack([s.key.key for s in sks]).astype(np.int32), "in0": x, "in1": y, "out": out,
             "plain": tfhe.mk_decrypt(sks, out).astype(np.uint8)})
     else:
-        p = tfhe.SchemeParameters(8, 1 / 2**15, 1024, 1, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1)
+        p = tfhe.SchemeParameters(8, 1 / 2**15, N, 1, 2, 10, 9e-9, 8, 2, 1 / 2**15, 1)
         sk, ck = tfhe.make_key_pair(rng, p)
-        o = orc.Oracle(8, 1024, 1, 2, 10, 8, 2)
+        o = orc.Oracle(8, N, 1, 2, 10, 8, 2)
         o.load_bootstrap_key(ck.bootstrap_key)
         o.load_keyswitch_key(ck.keyswitch_key)
         names = ["NAND", "OR", "AND", "XOR", "XNOR", "NOT", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "CONST0", "CONST1"]
@@ -178,18 +179,20 @@ def _mint_twin(tfhe, orc, path, multikey):
             "ops": ops, "in0": ins[0], "in1": ins[1], "in2": ins[2], "out": out, "plain": tfhe.decrypt(sk, out).astype(np.uint8)})
 
 
+@pytest.mark.parametrize("N", [1024, 512])
 @pytest.mark.parametrize("multikey", [False, True], ids=["single-key", "multi-key"])
-def test_fixture_reader_on_python_twin(tfhe, orc, tmp_path, multikey):
+def test_fixture_reader_on_python_twin(tfhe, orc, tmp_path, multikey, N):
     from tfhe_jl_amd.serialize import read_sections
     f = str(tmp_path / "twin.tfhe")
-    _mint_twin(tfhe, orc, f, multikey)
+    _mint_twin(tfhe, orc, f, multikey, N)
     check_reference_fixture(read_sections(f), tfhe, orc, gpu=False)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [1024, 512])
 @pytest.mark.parametrize("multikey", [False, True], ids=["single-key", "multi-key"])
-def test_fixture_reader_on_python_twin_gpu(tfhe, orc, tmp_path, multikey):
+def test_fixture_reader_on_python_twin_gpu(tfhe, orc, tmp_path, multikey, N):
     from tfhe_jl_amd.serialize import read_sections
     f = str(tmp_path / "twin.tfhe")
-    _mint_twin(tfhe, orc, f, multikey)
+    _mint_twin(tfhe, orc, f, multikey, N)
     check_reference_fixture(read_sections(f), tfhe, orc, gpu=True)

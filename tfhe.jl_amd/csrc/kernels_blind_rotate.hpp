@@ -1905,130 +1905,12 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
     if (tid_e == 0) ext[kN2] = acc_lds[kImg2 + kMir];
 }
 
-// ---- N = 2048, ONE wave per rotation (round 5, the round-4 verdict's bounded experiment) -------------------------------------
-// blind_rotate_kernel_n2048x splits every transform over two waves by a radix-2 stage: two barriers and one 8 KB exchange per
-// step, and both waves decompose all four coefficient classes of a polynomial.  Here ONE wave runs both halves of the split one
-// after the other (each half is the 512-point transform of the N = 1024 kernels): no barrier, no exchange, every digit extracted
-// once.  The price: all four output half-spectra stay in registers (128) beside both halves' pass-A twiddles (64) and the digit
-// values of a transform pair (64), so the kernel needs more than 256 registers — one wave per SIMD, four rotations per CU, the
-// same residency as the two-wave kernel at two waves per SIMD, but nobody to issue while this wave waits.  RW rotations per
-// workgroup in lockstep (one barrier every kV3SyncEvery steps) share their key fetches as in blind_rotate_kernel_v3.
-// Measured against n2048x<3, rw2> in tools/ab ... see DESIGN 4.2b; selected by option "n2048_one_wave" only.
-constexpr int kN2048oLdsBytes = 2 * kImg2 * 4 + kXchElems * (int)sizeof(cplx);     // per rotation (+ 64 cplx of pass-B twiddles per workgroup)
-template <int L, bool MARGIN = false, int RW = 4>
-__global__ __launch_bounds__(64 * RW, 1) void blind_rotate_kernel_n2048o(Br2048Args P)
-{
-    constexpr int K1 = 2;
-    unsigned long long dg_t0 = 0, dg_r0 = 0;
-    diag_begin<MARGIN>(dg_t0, dg_r0);
-    double worst = 0.0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wib = RW > 1 ? wave_in_block() : 0;
-    const int lane = (int)threadIdx.x & 63;
-    int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + (size_t)wib * kN2048oLdsBytes);          // [K1][kImg2]
-    cplx *xch = reinterpret_cast<cplx *>(smem + (size_t)wib * kN2048oLdsBytes + K1 * kImg2 * 4);   // [kXchElems]
-    cplx *tw2_lds = reinterpret_cast<cplx *>(smem + (size_t)RW * kN2048oLdsBytes);                 // [8][8]
-    const size_t w_raw = (size_t)blockIdx.x * RW + wib;
-    const bool live = w_raw < (size_t)P.R;
-    const size_t w = live ? w_raw : (size_t)P.R - 1;
-    const int32_t *bara = P.bara + w * (P.n + 1);
-    const int beta = P.g.log2_base;
-    const int32_t xormask = gadget_xor_mask(L, beta);
-
-    cplx tw1f[2][8];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int q = 0; q < 8; q++) tw1f[h][q] = P.tw1f2[h * 512 + q * 64 + lane];
-    if (threadIdx.x < 64) tw2_lds[threadIdx.x] = P.tw2[threadIdx.x];
-    {
-        const int barb = bara[P.n] & (2 * kN2 - 1);
-        int32_t v[32];
-#pragma unroll
-        for (int m = 0; m < 32; m++) v[m] = 0;
-        store_cur<32>(lane, v, acc_lds);
-#pragma unroll
-        for (int m = 0; m < 32; m++) {
-            const int idx = (lane + 64 * m + barb) & (2 * kN2 - 1);
-            v[m] = (idx & kN2) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
-        }
-        store_cur<32>(lane, v, acc_lds + kImg2);
-    }
-    __syncthreads();
-
-    int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
-#pragma unroll 1
-    for (int i = 0; i < P.n; i++) {
-        if (RW > 1 && (i % kV3SyncEvery) == 0) __builtin_amdgcn_s_barrier();
-        const int a = a_next;
-        a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);
-        const cplx *key = P.bk + (size_t)i * (L * K1 * K1 * 2 * kM) + lane;      // [p][c][co][h][8][64]
-        cplx out[K1][2][8];
-#pragma unroll
-        for (int d = 0; d < K1; d++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) out[d][h][q] = mk(0.0, 0.0);
-#pragma unroll 1
-        for (int c = 0; c < K1; c++) {
-            int32_t temp[32];
-            rotate_poly<32>(lane, a, acc_lds + c * kImg2, P.g.offset, xormask, temp);
-#pragma unroll 1
-            for (int p = 0; p < L; p++) {
-                // the four coefficient classes of point t + 64 r, extracted and converted once for both halves
-                double lo[8], hi[8], s2[8], d2[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int32_t l1 = digit2(temp[r], p + 1, beta), l2 = digit2(temp[r + 8], p + 1, beta);
-                    const int32_t h1 = digit2(temp[r + 16], p + 1, beta), h2 = digit2(temp[r + 24], p + 1, beta);
-                    lo[r] = (double)l1; hi[r] = (double)h1; s2[r] = (double)(l2 - h2); d2[r] = (double)(l2 + h2);
-                }
-                const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM;
-                static_for<0, 2>([&](auto hc) {
-                    constexpr int H = decltype(hc)::value;
-                    constexpr double sg = H ? -0.70710678118654752440 : 0.70710678118654752440;
-                    cplx x[8];
-                    static_for<0, 8>([&](auto rc) {
-                        constexpr int R = decltype(rc)::value;
-                        x[R] = fwd_in_2048<R>(lo[R], hi[R], s2[R], d2[R], sg, H != 0);
-                    });
-                    cplx kv[8];
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)H * kM + k2 * 64];                      // co = 0, requested before the transform
-                    fft_fwd_wave(lane, x, tw1f[H], tw2_lds, xch);
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[0][H][k2] = cfma(x[k2], kv[k2], out[0][H][k2]);
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)(2 + H) * kM + k2 * 64];                // co = 1
-#pragma unroll
-                    for (int k2 = 0; k2 < 8; k2++) out[1][H][k2] = cfma(x[k2], kv[k2], out[1][H][k2]);
-                    WAVE_LDS_FENCE();
-                });
-            }
-        }
-#pragma unroll
-        for (int co = 0; co < K1; co++) {
-            fft_inv_wave(lane, out[co][0], tw1f[0], tw2_lds, xch);
-            WAVE_LDS_FENCE();
-            fft_inv_wave(lane, out[co][1], tw1f[1], tw2_lds, xch);
-            WAVE_LDS_FENCE();
-            finish_2048<MARGIN>(lane, out[co][0], out[co][1], acc_lds + co * kImg2, worst);
-        }
-        WAVE_LDS_FENCE();
-    }
-    if (!live) return;
-    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0, lane == 0);
-    int32_t *ext = P.ext + w * (kN2 + 1);
-#pragma unroll
-    for (int m = 0; m < 32; m++) {
-        const int j = lane + 64 * m;
-        const int32_t v = acc_lds[kMir + j];
-        if (j == 0) ext[0] = v;
-        else ext[kN2 - j] = (int32_t)(0u - (uint32_t)v);
-    }
-    if (lane == 0) ext[kN2] = acc_lds[kImg2 + kMir];
-}
+// (Round 5, measured and removed — commit "Experiment: one wave per rotation at N = 2048": ONE wave running both halves of the
+//  radix-2 split one after the other, all four output half-spectra in registers — no barrier, no exchange, every digit extracted
+//  once, but 256 VGPRs + 181 AGPRs of spill space and one wave per SIMD with nobody to issue while it waits: 65.9 vs 46.2 ms per
+//  4096 rotations of config 4b on one device, 132.0 vs 88.5 at 8192, 14.4 vs 6.8 for a single rotation
+//  (profiles/r05/r05h_n2048_one_wave.jsonl).  The two barriers and the exchange of the two-wave kernel cost less than a second
+//  wave per SIMD is worth.)
 
 // ---- any single-key parameter set (round 4): run-time mask size k <= 4 and decomposition length l, N = 1024 or 2048 ----
 // SchemeParameters is an unvalidated struct and tlwe_mask_size a free keyword in the reference (api.jl:4-21,30,55): a

@@ -157,7 +157,6 @@ struct tfhe_ctx {
     DevBuf bara, ext, map, io[4], diag, abar, mk_acc, spec;
     size_t diag_rows = 0;
     bool mk_force_general = false; // tfhe_set_option("mk_general", 1): use the any-P kernel for 2 parties too (cross-check)
-    int n2048_one_wave = 0;        // tfhe_set_option("n2048_one_wave", 1): N = 2048 on ONE wave per rotation (blind_rotate_kernel_n2048o, round 5's experiment) instead of two
     int n2048_rw = 0;              // N = 2048: rotations per workgroup advancing in lockstep (tfhe_set_option("n2048_rw", 0|1|2); 0 = one up to
                                    //  one rotation per CU — the pair would leave half the CUs idle: 7.9 vs 9.0 ms at 64 rotations — two beyond)
     int mkg_rw = 0;                // any-party kernel: rotations per workgroup, in lockstep (0: two; otherwise a cap, at most 4 and what fits in LDS)
@@ -972,19 +971,6 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         Br2048Args b;
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
-        if (c->n2048_one_wave) {
-            // the one-wave-per-rotation experiment (blind_rotate_kernel_n2048o; option "n2048_one_wave"): four rotations per
-            // workgroup in lockstep, one workgroup per CU; single-rotation workgroups up to one rotation per CU and under DIAG
-            const int rwo = (dg || R <= (size_t)c->cu_count) ? 1 : 4;
-            const size_t ldso = (size_t)rwo * kN2048oLdsBytes + 64 * sizeof(cplx);
-            const unsigned nblko = (unsigned)((R + rwo - 1) / rwo);
-            if (dg) { LDS_TRY(c, ldso, blind_rotate_kernel_n2048o<3, true, 1>); hipLaunchKernelGGL((blind_rotate_kernel_n2048o<3, true, 1>), dim3(nblko), dim3(64), ldso, s, b); }
-            else if (rwo == 1) { LDS_TRY(c, ldso, blind_rotate_kernel_n2048o<3, false, 1>); hipLaunchKernelGGL((blind_rotate_kernel_n2048o<3, false, 1>), dim3(nblko), dim3(64), ldso, s, b); }
-            else { LDS_TRY(c, ldso, blind_rotate_kernel_n2048o<3, false, 4>); hipLaunchKernelGGL((blind_rotate_kernel_n2048o<3, false, 4>), dim3(nblko), dim3(256), ldso, s, b); }
-            HIP_TRY(c, hipGetLastError());
-            name_kernel(c, "blind_rotate_kernel_n2048o<%d,rw%d>", L, rwo);
-            return TFHE_OK;
-        }
         const int rw = dg ? 1 : c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);     // (the DIAG instantiation exists for single rotations only)
         const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
@@ -1789,7 +1775,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
     t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
-    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3; t->n2048_one_wave = c->n2048_one_wave;
+    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3;
     return TFHE_OK;
 }
 
@@ -2755,7 +2741,7 @@ int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value)
         {"br_split", c->br_split}, {"br_general", c->br_general}, {"br_anyn", c->br_anyn}, {"anyn_spec", c->anyn_spec},
         {"level_split_min", c->level_split_min}, {"level_exchange", c->level_exchange}, {"br_prio_pct", c->br_prio_pct}, {"ks_slices", c->ks_slices_large},
         {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3},
-        {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"n2048_one_wave", c->n2048_one_wave}, {"mkg_acc", c->mkg_acc},
+        {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"mkg_acc", c->mkg_acc},
         {"mkg_variant", c->mkg_variant}, {"mkg_rw", c->mkg_rw}, {"mk_rw", c->mk_rw}, {"ks_variant", c->ks_variant},
     };
     for (const auto &e : table)
@@ -2838,7 +2824,6 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
         return TFHE_OK;
     }
     if (!strcmp(name, "mk_general")) { c->mk_force_general = value != 0; return TFHE_OK; }
-    if (!strcmp(name, "n2048_one_wave")) { c->n2048_one_wave = value != 0; return TFHE_OK; }
     if (!strcmp(name, "n2048_rw")) {
         if (value != 0 && value != 1 && value != 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n2048_rw must be 0 (by batch size), 1 or 2");
         c->n2048_rw = (int)value;
