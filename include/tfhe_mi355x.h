@@ -62,8 +62,10 @@
  * bs_log2_base — and (ii) every pre-rounding value v satisfies |v| < 2^51: the kernels round with the 1.5 * 2^52 trick, exact
  * there; the reference's round(Int64, .) is defined up to 2^63 but has lost integer precision long before.  With a real key
  * (uniform words) |v| is around sqrt((k+1) l N) * 2^(bs_log2_base + 29) = 2^44 at the 80-bit set; only a caller-supplied
- * "key" whose words all share one sign at magnitude 2^31 reaches 2^52 (k = 1, l = 2, beta = 10, N = 1024), where neither
- * this engine nor the reference computes the exact product (tests/test_any_params.py::test_worst_case_magnitude_key).
+ * "key" whose words all share one sign at magnitude 2^31 reaches 2^52 (k = 1, l = 2, beta = 10, N = 1024): outside the domain,
+ * no guarantee there from this engine or from the reference (tests/test_any_params.py::test_worst_case_magnitude_key feeds
+ * such a key and records what comes out: with every word -2^31 the values are multiples of 2^31, which Float64 still holds
+ * exactly, and both still return the exact product; full-range random words with the extremes planted are exact as any key).
  */
 #ifndef TFHE_MI355X_H
 #define TFHE_MI355X_H
