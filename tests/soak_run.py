@@ -2,7 +2,9 @@
 """Soak run (lives under tests/ because it uses the oracle as the checker; not collected by pytest — run it as
 `python tests/soak_run.py [iterations]` on a GPU box): random batch sizes and opcode mixes against the oracle (every output word for small batches, a random
 sample for large ones) plus decrypt checks, alternating the host-buffer API, the wire-table level API and — on a
-{0, 0} multi-device context — streamed submits and sharded levels."""
+{0, 0} multi-device context — streamed submits, sharded levels and CHAINS of dependent sharded levels (every level reading a
+random selection of what earlier levels wrote on either device context, with the exchange path and the split threshold drawn at
+random) against the same chain on one device, every wire of the table."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
@@ -28,7 +30,33 @@ for it in range(iters):
     ops = np.array([tfhe.OPCODES[names[s]] for s in sel], np.uint8)
     bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
     ins = [tfhe.encrypt(K.rng, K.sk, b).data for b in bits]
-    mode = ("batch", "level", "multi-submit", "multi-level")[it % 4]
+    mode = ("batch", "level", "multi-submit", "multi-level", "multi-chain")[it % 5]
+    if mode == "multi-chain":
+        # 3 .. 6 dependent levels over a table of W wires; level t writes a fresh block of wires and reads any earlier ones
+        W0 = int(rng.integers(8, 200))
+        depth = int(rng.integers(3, 7))
+        widths = [int(rng.integers(1, 150)) for _ in range(depth)]
+        total = W0 + sum(widths)
+        base = tfhe.encrypt(K.rng, K.sk, rng.integers(0, 2, W0).astype(bool)).data
+        multi.set_option("level_exchange", int(rng.integers(0, 3)))
+        multi.set_option("level_split_min", int(rng.choice([2, 16, 64, 4096])))
+        levels, have = [], W0
+        for wdt in widths:
+            lops = np.array([tfhe.OPCODES[names[s_]] for s_ in rng.integers(0, len(names), wdt)], np.uint8)
+            levels.append((lops, *(rng.integers(0, have, wdt).astype(np.int32) for _ in range(3)), np.arange(have, have + wdt, dtype=np.int32)))
+            have += wdt
+        tables = []
+        for e in (eng, multi):
+            e.wires_alloc(total)
+            e.wires_upload(0, base)
+            for lops, a_, b_, c_, o_ in levels:
+                e.gates_level(lops, a_, b_, c_, o_)
+            tables.append(e.wires_gather(np.arange(total, dtype=np.int32)))
+        assert np.array_equal(tables[0], tables[1]), f"iter {it}: multi-device chain differs from one device"
+        multi.set_option("level_exchange", 0)
+        multi.set_option("level_split_min", 64)
+        print(f"iter {it:3d} chain of {depth} levels, {total} wires ok", flush=True)
+        continue
     if mode == "batch":
         got = eng.gates(ops, *ins)
     elif mode == "multi-submit":             # two device contexts, every one takes its shard as a submit of its own

@@ -17,6 +17,7 @@
 // integer (the DIAG instantiation measures that distance, as for every other kernel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "br_core.hpp"
 #include "kernels_blind_rotate.hpp"
@@ -172,13 +173,20 @@ __host__ __device__ inline size_t lds_bytes(int N, int nspec_in_lds)
 }
 __host__ inline int threads_for(int N)
 {
-    const int b = N / 16;                     // radix-8 butterflies per stage
-    return b <= 64 ? 64 : b >= 256 ? 256 : b;
+    // (measurement aid: TFHE_ANYN_THREADS overrides)
+    static const char *env = getenv("TFHE_ANYN_THREADS");
+    if (env && atoi(env) >= 64) return atoi(env) > 512 ? 512 : atoi(env) / 64 * 64;
+    // Measured (profiles/r05/r05j_anyn_threads.txt; blind rotate of 4096 / 2048 / 1024 / 512 gates at N = 512 / 1024 / 2048 / 4096):
+    //   N = 512:  64 threads 35.3 ms, 128: 30.7, 256: 38.3      N = 1024: 64: 45.9, 128: 32.1, 256: 26.7, 512: 38.3
+    //   N = 2048: 128: 92.4, 256: 65.7, 512: 54.9                 N = 4096: 64: 323, 128: 176, 256: 111-113, 512: 81.4
+    // A radix-8 stage has only N/16 butterflies, but the element-wise phases (rotate, digits, products, untwist) and the number of
+    // waves a CU can interleave grow with the workgroup.
+    return N <= 256 ? 64 : N == 512 ? 128 : N == 1024 ? 256 : 512;
 }
 
 // ---- single key (bootstrap.jl:19-82, tgsw.jl:99-129) --------------------------------------------------------------
 template <bool MARGIN>
-__global__ __launch_bounds__(256) void blind_rotate_kernel(Args P)
+__global__ __launch_bounds__(512) void blind_rotate_kernel(Args P)
 {
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void blind_rotate_kernel(Args P)
 // Three spectrum accumulators are live whatever P is: a'_s of a non-party source is fed by its own digits only and nobody
 // else reads acc[s] in this step, so it is finished right after source s.
 template <bool MARGIN>
-__global__ __launch_bounds__(256) void mk_blind_rotate_kernel(Args P)
+__global__ __launch_bounds__(512) void mk_blind_rotate_kernel(Args P)
 {
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(256) void mk_blind_rotate_kernel(Args P)
 
 // ---- bootstrapping-key preparation --------------------------------------------------------------------------------
 // Int32 polynomial -> spectrum in fft_fwd's order, scaled (1/M for key polynomials: forward_transform.(bk), bootstrap.jl:12)
-__global__ __launch_bounds__(256) void bk_prepare_kernel(const int32_t *__restrict__ polys, cplx *__restrict__ out, const cplx *__restrict__ wtab,
+__global__ __launch_bounds__(512) void bk_prepare_kernel(const int32_t *__restrict__ polys, cplx *__restrict__ out, const cplx *__restrict__ wtab,
                                                          const cplx *__restrict__ twist, int log2N, double scale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -397,7 +405,7 @@ struct MkExpandArgs {
     const cplx *wtab, *twist;
     int32_t n, l, parties, party, log2N;
 };
-__global__ __launch_bounds__(256) void mk_expand_kernel(MkExpandArgs A)
+__global__ __launch_bounds__(512) void mk_expand_kernel(MkExpandArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx *buf = reinterpret_cast<cplx *>(smem);
