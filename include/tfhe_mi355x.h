@@ -43,11 +43,11 @@
  * What runs where (every path gives the same words):
  *   tuned kernels      N = 1024 with k = 1 and ANY l (instantiated for the shipped l = 2 and 3; the one- and two-waves-per-rotation
  *                      kernels also exist with l as a run-time value and serve every other l at the same speed); N = 1024 with
- *                      k = 2 and l = 2 or 3; N = 2048 with k = 1 and l = 3 (BASELINE config 4b); multi-key N = 1024: the shipped
- *                      2- / 4- / 8-party sets
+ *                      k = 2 and l = 2 or 3; N = 2048 with k = 1 and l = 3 (BASELINE config 4b); N = 512 with k = 1 and any l (the
+ *                      same design with four points per lane); multi-key N = 1024: the shipped 2- / 4- / 8-party sets
  *   general kernels    everything else at N = 1024 / 2048 with k <= 4 (blind_rotate_kernel_general, ~3.5 x slower than tuned),
  *                      multi-key at N = 1024 with up to 8 parties and l <= 8 (mk_blind_rotate_kernel_general)
- *   any-N kernels      every other set (N other than 1024 / 2048, k > 4, multi-key with N other than 1024, more than 8 parties or
+ *   any-N kernels      every other set (N other than 512 / 1024 / 2048, N = 512 with k > 1, k > 4, multi-key with N other than 1024, more than 8 parties or
  *                      l > 8): csrc/kernels_anyn.hpp, one workgroup per rotation, mixed-radix transforms in LDS — correct, untuned
  *   keyswitch          int8 MFMA kernel for base 4 / t = 8 (k N a multiple of 128), tiled integer kernel for base 4 / t a
  *                      multiple of 4 (k N <= 2048), gather kernel for every other base, length and size (single- and multi-key)
@@ -147,7 +147,7 @@ void tfhe_ctx_destroy(tfhe_ctx *ctx);
  * tfhe_gates_batch_dev needs n_dev == 1 (a device pointer belongs to one device).  tfhe_gates_batch_submit gives every
  * device its shard as a submit of its own, so each keeps two batches in flight.  The wire table (tfhe_wires_*) is
  * replicated on every device; tfhe_gates_level runs a level of fewer than "level_split_min" blind rotations (option,
- * default 4096) on the first device and shards a wider one over all of them.  The context tracks which replicas hold each
+ * default 16 per compute unit of the first device: 4096 on an MI355X) on the first device and shards a wider one over all of them.  The context tracks which replicas hold each
  * wire's current value: a device fetches the operand rows it is about to read and does not have — device to device
  * (hipMemcpyPeerAsync; peer access is switched on at creation wherever hipDeviceCanAccessPeer allows) or through pinned host
  * memory where it does not (option "level_exchange": 0 = by peer access, 1 / 2 force either path) — on the devices' own streams,
@@ -300,7 +300,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *ctx, const int32_t *in0, const int32_t
 /* Timing of the most recent batch call on ctx, from HIP events recorded on the stream the kernels
  * were launched on.  which: 0 = blind-rotate kernel(s), 1 = keyswitch kernel(s), 2 = whole batch
  * (prologue .. last kernel, device side).  Blocks until those kernels have finished.  After a host-buffer call that ran as
- * two halves on two streams (tfhe_gates_batch from "pipeline_min" gates up): from the start of the phase on the stream that
+ * two halves on two streams (tfhe_gates_batch from "pipeline_min" gates up; default 16 per compute unit: 4096 on an MI355X): from the start of the phase on the stream that
  * started first to the later of the two streams' ends. */
 int32_t tfhe_last_timing_ms(tfhe_ctx *ctx, int32_t which, float *ms);
 

@@ -53,7 +53,7 @@ def _check_gates(tfhe, eng, K, what):
 
 
 ANY_N = [  # what, n, N, k, l, beta
-    ("N = 512 (half of the shipped degree)", 6, 512, 1, 2, 10),
+    ("N = 512, k = 2", 6, 512, 2, 2, 8),
     ("N = 4096", 4, 4096, 1, 3, 7),
     ("N = 256, k = 2", 6, 256, 2, 3, 6),
     ("N = 64", 5, 64, 1, 4, 4),
@@ -83,6 +83,40 @@ def test_any_polynomial_degree_and_mask_size(tfhe, orc, what, n, N, k, l, beta):
     _check_rotation(eng, K, x, f"blind_rotate_kernel_anyn(N={N},k={k},l={l},spec=global)", what + ", spectrum accumulators in global memory")
     eng.set_option("anyn_spec", -1)
     _check_gates(tfhe, eng, K, what)
+    K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l,beta", [(2, 10), (3, 7), (4, 6), (1, 9)])
+def test_n512_tuned_kernel(tfhe, orc, l, beta):
+    """blind_rotate_kernel_n512 (N = 512, k = 1: blind_rotate_kernel_v3's design with four points per lane, three waves per SIMD),
+    instantiated for l = 2 and 3 and with l read at run time for every other: blind rotation on arbitrary words + DIAG margin
+    against the oracle; the lockstep groups of four with a ragged count (padding waves); the same words as the any-N kernel
+    (option br_anyn); whole gates decrypted; the reference's spectra form of the key (a permutation into this kernel's order)."""
+    K = _setup(tfhe, orc, 6, 512, 1, l, beta, seed=l)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(512 + l), 6, 7)
+    name = f"blind_rotate_kernel_n512<{l}>" if l in (2, 3) else f"blind_rotate_kernel_n512<0>(l={l})"
+    margin = _check_rotation(eng, K, x, name, f"n512, l = {l}")
+    print(f"  rounding margin, N = 512 tuned kernel, l = {l}, beta = {beta}: {margin:.4f}")
+    eng.set_option("n512_rw", 4)              # 6 rotations = one full group + one with two padding waves
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == name.replace(">", ",rw4>", 1), eng.last_kernel_name()
+    assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
+    eng.set_option("n512_rw", 0)
+    e2 = tfhe.Engine(K.params, 0)
+    e2.set_option("br_anyn", 1)
+    e2.load_bootstrap_key(K.ck.bootstrap_key)
+    assert np.array_equal(e2.bootstrap(MU, x, with_keyswitch=False), got)
+    assert e2.last_kernel_name() == f"blind_rotate_kernel_anyn(N=512,k=1,l={l})"
+    e2.close()
+    e3 = tfhe.Engine(K.params, 0)
+    e3.load_bootstrap_key_spectra(K.oracle.bk_spectra())
+    assert np.array_equal(e3.bootstrap(MU, x, with_keyswitch=False), got)
+    assert e3.last_kernel_name() == name
+    e3.close()
+    if l >= 2:
+        _check_gates(tfhe, eng, K, f"n512, l = {l}")
     K.ck.close()
 
 
@@ -385,9 +419,9 @@ def test_timing_history_never_reports_the_slot_being_recorded(tfhe, keys80):
 
 @pytest.mark.gpu
 def test_n512_full_size_set(tfhe, orc):
-    """A full-size set on the any-N kernel: tfhe_parameters_80 with N = 512 (500 CMUX steps, keyswitch from 512 words on the MFMA
-    kernel), 1200 mixed gates: every output decrypts, 96 sampled rows equal the oracle word for word, the DIAG run gives the same
-    words with a margin below 0.25."""
+    """A full-size set outside the shipped degree: tfhe_parameters_80 with N = 512 (500 CMUX steps on blind_rotate_kernel_n512,
+    keyswitch from 512 words on the MFMA kernel), 1200 mixed gates: every output decrypts, 96 sampled rows equal the oracle word
+    for word, the DIAG run gives the same words with a margin below 0.25; 3500 rotations take the lockstep groups."""
     from conftest import KeySet
     b = tfhe.tfhe_parameters_80()
     p = tfhe.SchemeParameters(b.lwe_size, b.lwe_noise_stddev, 512, 1, b.bs_decomp_length, b.bs_log2_base, b.bs_noise_stddev,
@@ -402,7 +436,7 @@ def test_n512_full_size_set(tfhe, orc):
     bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
     ins = [tfhe.encrypt(K.rng, K.sk, v).data for v in bits]
     got = eng.gates(ops, *ins)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_anyn(N=512,k=1,l=2)"
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n512<2>"
     x, y, z = bits
     want = np.select([sel == 0, sel == 1, sel == 2, sel == 3, sel == 4], [~(x & y), x & y, x | y, x ^ y, np.where(x, y, z)])
     assert np.array_equal(tfhe.decrypt(K.sk, got), want)
@@ -414,4 +448,9 @@ def test_n512_full_size_set(tfhe, orc):
     eng.set_option("measure_margin", 0)
     assert np.array_equal(again, got[:64]) and 0.0 < margin < 0.25, margin
     print(f"  rounding margin, tfhe_parameters_80 with N = 512, full size: {margin:.4f}")
+    big = [np.tile(a, (3, 1))[:3500] for a in ins[:2]]
+    got_big = eng.gates(np.zeros(3500, np.uint8), *big)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n512<2,rw4>", eng.last_kernel_name()
+    first = eng.gates(np.zeros(B, np.uint8), ins[0], ins[1])
+    assert np.array_equal(got_big[:B], first) and np.array_equal(got_big[B:2 * B], first)
     K.ck.close()

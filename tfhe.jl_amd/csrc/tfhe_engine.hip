@@ -43,6 +43,7 @@ using namespace tfhe;
 #include "mk_g2_launch.hpp"
 #endif
 #include "kernels_anyn.hpp"
+#include "kernels_n512.hpp"
 #include "kernels_keyswitch.hpp"
 #include "kernels_keygen.hpp"
 
@@ -107,7 +108,7 @@ struct tfhe_ctx {
     int ks_slices_large = 2;     // K-split of the MFMA keyswitch for large batches (tfhe_set_option("ks_slices", 1|2|4))
     int ks_variant = 4;          // 1 = one workgroup per sample, 3 = tiled + sliced + XCD-aware integer VALU, 4 = int8 MFMA (default)
     int ks_mode = 0;             // kernel family the loaded keyswitch key was laid out for (decided at load: pick_ks_mode)
-    int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): 1024 is what the chip holds at two waves per SIMD
+    int64_t br_small = 1024;     // batches of at most this many rotations use the two-waves-per-rotation kernel (-1: never): what the chip holds at two waves per SIMD, 4 per CU (set at creation: 1024 on 256 CUs)
     int br_prio_pct = 90;        // a wave of the batched kernels lowers its issue priority 3 -> 0 over this share of its steps (0: off)
     int br_general = 0;          // tfhe_set_option("br_general", 1): every single-key blind rotation on blind_rotate_kernel_general (cross-check of the specialised kernels)
     int br_split = 1;            // tfhe_set_option("br_split", 0 | 1): batches above what the chip holds send their last, partly filled round (<= br_small rotations) to the two-waves-per-rotation kernels in a second launch (launch_blind_rotate)
@@ -133,8 +134,11 @@ struct tfhe_ctx {
     {
         if (br_anyn) return true;
         if (P.parties > 1) return P.N != kN || P.parties > 8 || P.bs_l > 8;
+        if (n512()) return false;
         return (P.N != kN && P.N != 2048) || P.k > 4;
     }
+    // N = 512 with k = 1 (any l) has a tuned kernel of its own (kernels_n512.hpp) and its own key order
+    bool n512() const { return !br_anyn && P.parties == 1 && P.N == 512 && P.k == 1; }
 
     // keys (only the layout of the selected keyswitch kernel family stays resident)
     cplx *d_bk = nullptr;       size_t bk_polys = 0;
@@ -184,6 +188,7 @@ struct tfhe_ctx {
     std::vector<int32_t> kid_tickets[2];  // multi-device context: per submit slot, the ticket every kid gave for its shard (2: none)
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
+    int n512_rw = 0;             // tfhe_set_option("n512_rw", 0 | 1 | 4): rotations per workgroup of the N = 512 kernel (0: by batch size)
     int k2_w3 = -1;              // tfhe_set_option("k2_w3", -1 | 0 | 1): the three-waves-per-rotation k = 2 kernel for batches of up to two rotations per CU and for the last round of a larger one (-1: by size), never (0), for every batch (1)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
     int v3_rw = 0;               // tfhe_set_option("v3_rw", 0 | 1 | 4): rotations per workgroup of the default kernel; 0 = 4 from 1536 rotations up
@@ -283,10 +288,11 @@ static int32_t ensure_dyn_lds(tfhe_ctx *c, const void *fn, size_t bytes, const c
     } while (0)
 
 constexpr size_t kH2TableOffset = kTableElems + 1024;      // tw1h | tw2q | tw3q of blind_rotate_kernel_h2
+constexpr size_t kN512TableOffset = kH2TableOffset + kH2TableElems;      // tw1 of blind_rotate_kernel_n512
 
 static void build_tables(std::vector<cplx> &h)
 {
-    h.resize(kH2TableOffset + kH2TableElems);
+    h.resize(kN512TableOffset + kN512TableElems);
     fill_tables<long double>(h.data(), [](long double a) { return cosl(a); }, [](long double a) { return sinl(a); });
     // N = 2048: tw1f2[w][q][t] = e^{-i pi t (1 + 4w + 8q) / 2048}
     const long double pi = 3.14159265358979323846264338327950288L;
@@ -306,6 +312,9 @@ static void build_tables(std::vector<cplx> &h)
         for (int t = 0; t < 16; t++) put(kH2TableOffset + 512 + (size_t)q * 16 + t, (long double)(t * q) / 32.0L);      // e^{-2 pi i t q/64}
     for (int q = 0; q < 4; q++)
         for (int t = 0; t < 4; t++) put(kH2TableOffset + 576 + (size_t)q * 4 + t, (long double)(t * q) / 8.0L);          // e^{-2 pi i t q/16}
+    // N = 512 (blind_rotate_kernel_n512): first-pass twiddles with the lane part of that degree's twist: e^{-i pi t/512} e^{-2 pi i t q/256}
+    for (int q = 0; q < 4; q++)
+        for (int t = 0; t < 64; t++) put(kN512TableOffset + (size_t)q * 64 + t, (long double)t / 512.0L + (long double)(t * q) / 128.0L);
 }
 
 static int ilog2i(int x) { int r = 0; while ((1 << r) < x) r++; return r; }
@@ -407,6 +416,13 @@ int32_t tfhe_ctx_create(const tfhe_params *params, int32_t device_id, tfhe_ctx *
         int cus = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess) return bail(e, "hipDeviceGetAttribute");
         c->cu_count = cus > 0 ? cus : 256;
+        // the batch-size thresholds of the dispatcher are counts of rotations PER CU measured on a 256-CU MI355X; they are kept in
+        // those units so that a partitioned device (CPX: 32 CUs per partition) or another part of the family switches kernels at
+        // the same fill levels: 4 per CU = what the chip holds of the two-wave kernel at two waves per SIMD (1024 on 256 CUs),
+        // 16 per CU = two rounds of the one-wave kernel (4096).  tfhe_set_option overrides them with absolute counts.
+        c->br_small = 4 * (int64_t)c->cu_count;
+        c->pipeline_min = 16 * (int64_t)c->cu_count;
+        c->level_split_min = 16 * (int64_t)c->cu_count;
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     for (auto &set : c->evring)
@@ -459,6 +475,8 @@ int32_t tfhe_ctx_create_multi(const tfhe_params *params, const int32_t *device_i
         c->kids.push_back(k);
     }
     c->kid_ran.assign((size_t)n_dev, 0);
+    c->cu_count = c->kids[0]->cu_count;
+    c->level_split_min = c->kids[0]->level_split_min;
     // Device-to-device copies between the replicas of the wire table (pull_wires): allowed between two kids on the same
     // device and wherever hipDeviceCanAccessPeer says so; peer access is switched on for those pairs here, once.  Pairs
     // without it exchange rows through pinned host memory instead.
@@ -661,7 +679,12 @@ static int32_t load_bk_common(tfhe_ctx *c, const void *host, size_t bytes_in, bo
     void *d_in = nullptr;
     HIP_TRY(c, hipMalloc(&d_in, bytes_in));
     hipError_t e = hipMemcpyAsync(d_in, host, bytes_in, hipMemcpyDefault, c->stream)   /* host pointer, or a device buffer (tfhe_keygen_cloud_key) */;
-    if (e == hipSuccess && c->anyn()) {
+    if (e == hipSuccess && c->n512()) {
+        const cplx *t1 = c->d_tables + kN512TableOffset, *t2 = c->d_tables + kH2TableOffset + 512, *t3 = t2 + 64;
+        if (is_c128) hipLaunchKernelGGL(bk_permute_c128_kernel_n512, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const cplx *)d_in, c->d_bk);
+        else hipLaunchKernelGGL(bk_prepare_kernel_n512, dim3((unsigned)npolys), dim3(64), 0, c->stream, (const int32_t *)d_in, c->d_bk, t1, t2, t3);
+        e = hipGetLastError();
+    } else if (e == hipSuccess && c->anyn()) {
         // the any-N kernels' spectrum order (kernels_anyn.hpp): the same forward transform they run, or a permutation of the reference's spectra
         const int log2N = ilog2i(c->P.N), M = c->P.N / 2;
         if (is_c128) {
@@ -939,6 +962,26 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         name_kernel(c, spec_lds ? "blind_rotate_kernel_anyn(N=%d,k=%d,l=%d)" : "blind_rotate_kernel_anyn(N=%d,k=%d,l=%d,spec=global)", N, c->P.k, L);
         return TFHE_OK;
     }
+    if (c->n512()) {
+        // N = 512, k = 1: blind_rotate_kernel_v3's design with four points per lane (kernels_n512.hpp), three waves per SIMD;
+        // four rotations per workgroup in lockstep once the batch fills the chip (option n512_rw)
+        N512Args b;
+        b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.g = c->g; b.n = a.n; b.mu = mu; b.R = (int32_t)R; b.l = L;
+        b.prio_steps = a.prio_steps;
+        b.tw1 = c->d_tables + kN512TableOffset; b.tw2q = c->d_tables + kH2TableOffset + 512; b.tw3q = b.tw2q + 64;
+        const bool group = !dg && (c->n512_rw == 4 || (c->n512_rw == 0 && R >= 12 * (size_t)c->cu_count));
+        const size_t lds5 = (size_t)(group ? 4 : 1) * kN512LdsBytes;
+#define LAUNCH_N512(LL)                                                                                            \
+        if (dg) hipLaunchKernelGGL((blind_rotate_kernel_n512<LL, true, 1>), dim3((unsigned)R), dim3(64), lds5, s, b);            \
+        else if (group) hipLaunchKernelGGL((blind_rotate_kernel_n512<LL, false, 4>), dim3((unsigned)((R + 3) / 4)), dim3(256), lds5, s, b); \
+        else hipLaunchKernelGGL((blind_rotate_kernel_n512<LL, false, 1>), dim3((unsigned)R), dim3(64), lds5, s, b)
+        BR_CASES_ANY_L(LAUNCH_N512)
+#undef LAUNCH_N512
+        HIP_TRY(c, hipGetLastError());
+        if ((L == 2 || L == 3) && !c->br_rt_l) name_kernel(c, group ? "blind_rotate_kernel_n512<%d,rw4>" : "blind_rotate_kernel_n512<%d>", L);
+        else name_kernel(c, group ? "blind_rotate_kernel_n512<0,rw4>(l=%d)" : "blind_rotate_kernel_n512<0>(l=%d)", L);
+        return TFHE_OK;
+    }
     const bool tuned = c->P.N == kN2 ? (c->P.k == 1 && L == 3) : c->P.k == 1 ? true : (c->P.k == 2 && (L == 2 || L == 3));
     if (!tuned || c->br_general) {
         // any (k <= 4, l, N): one wave per rotation, accumulator images in global memory, spectrum accumulators in LDS
@@ -1086,7 +1129,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         // (round 3's <l, 16> / <l, 8, tw2 in LDS> variants were A/B scaffolding and are gone); four rotations per workgroup in
         // lockstep once the batch puts two waves on most SIMDs (option v3_rw: 0 = by batch size, 1, 4)
         const size_t lds3 = kV3LdsBytes;
-        const bool group = c->v3_rw == 4 || (c->v3_rw == 0 && R >= 1536);      // (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
+        const bool group = c->v3_rw == 4 || (c->v3_rw == 0 && R >= 6 * (size_t)c->cu_count);      // 1536 on 256 CUs (1400 rotations: 5.47 vs 5.40 ms, 1700: 5.50 vs 5.66, 2000: 5.69 vs 5.93)
 #define LAUNCH_V3_GROUP(LL, DG)                                                                                    \
         do {                                                                                                       \
             LDS_TRY(c, (4 * lds3), blind_rotate_kernel_v3<LL, 8, true, DG, 4>); \
@@ -1328,6 +1371,8 @@ static int32_t run_gates(tfhe_ctx *c, const char *who, const uint8_t *opcodes, i
                          const int32_t *d_in1, const int32_t *d_in2, int32_t *d_out, const int32_t *ia, const int32_t *ib,
                          const int32_t *ic, const int32_t *io, hipStream_t s)
 {
+    // development aid (TFHE_DEBUG_HOSTTIME=1): host microseconds per section of this function, printed per call — what showed that a
+    // circuit level's host time was the wait for the previous level's staging copy, not anything in here (round 5)
     static const bool dbg_host = getenv("TFHE_DEBUG_HOSTTIME") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1499,7 +1544,7 @@ int32_t tfhe_wires_upload(tfhe_ctx *c, int64_t first, int64_t count, const int32
         const int32_t rc0 = wires_range_ok(c, "wires_upload", first, count, host);
         if (rc0 || count == 0) return rc0;
         const int32_t rc = fan_out(c, all_kids(c), [&](int k) { return tfhe_wires_upload(c->kids[(size_t)k], first, count, host); });
-        for (size_t k = 0; k < c->kids.size(); k++)      // (on failure: valid nowhere but where the old value's owner says — mark them all stale except the owner's view is gone too; re-upload is the remedy)
+        for (size_t k = 0; k < c->kids.size(); k++)      // (after a failed upload the range is current nowhere: the caller got the error and uploads again)
             std::fill(c->wire_valid[k].begin() + first, c->wire_valid[k].begin() + first + count, rc == TFHE_OK ? 1 : 0);
         if (rc == TFHE_OK) std::fill(c->wire_owner.begin() + first, c->wire_owner.begin() + first + count, 0);
         return rc;
@@ -1775,7 +1820,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
     t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
-    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3;
+    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3; t->n512_rw = c->n512_rw;
     return TFHE_OK;
 }
 
@@ -2740,7 +2785,7 @@ int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value)
         {"br_small", c->br_small}, {"br_tiny", c->br_tiny}, {"br_rt_l", c->br_rt_l}, {"timing_events", c->timing_events},
         {"br_split", c->br_split}, {"br_general", c->br_general}, {"br_anyn", c->br_anyn}, {"anyn_spec", c->anyn_spec},
         {"level_split_min", c->level_split_min}, {"level_exchange", c->level_exchange}, {"br_prio_pct", c->br_prio_pct}, {"ks_slices", c->ks_slices_large},
-        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3},
+        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3}, {"n512_rw", c->n512_rw},
         {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"mkg_acc", c->mkg_acc},
         {"mkg_variant", c->mkg_variant}, {"mkg_rw", c->mkg_rw}, {"mk_rw", c->mk_rw}, {"ks_variant", c->ks_variant},
     };
@@ -2801,6 +2846,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "w2_rw")) {
         if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: w2_rw must be 0 (by batch size), 1 or 2");
         c->w2_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "n512_rw")) {
+        if (value != 0 && value != 1 && value != 4) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n512_rw must be 0 (by batch size), 1 or 4");
+        c->n512_rw = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "k2_w3")) {
