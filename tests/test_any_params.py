@@ -453,4 +453,11 @@ def test_n512_full_size_set(tfhe, orc):
     assert eng.last_kernel_name() == "blind_rotate_kernel_n512<2,rw4>", eng.last_kernel_name()
     first = eng.gates(np.zeros(B, np.uint8), ins[0], ins[1])
     assert np.array_equal(got_big[:B], first) and np.array_equal(got_big[B:2 * B], first)
+    # from pipeline_min gates up a host-buffer batch runs as two halves on two streams (the second on a twin context that borrows
+    # this context's keys and has its own tables): same words
+    huge = [np.tile(a, (4, 1))[:4400] for a in ins[:2]]
+    got_huge = eng.gates(np.zeros(4400, np.uint8), *huge)
+    for r in range(3):
+        assert np.array_equal(got_huge[r * B:(r + 1) * B], first), r
+    assert np.array_equal(got_huge[3 * B:], first[:4400 - 3 * B])
     K.ck.close()

@@ -1,5 +1,7 @@
+"""Host time inside the raw tfhe_gates_level ccall per circuit level (16-MUX levels back to back): what showed that the call blocks
+only once the host is four levels ahead (the ring of pinned staging blocks)."""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tfhe_jl_amd as tfhe
 rng = np.random.default_rng(5)
