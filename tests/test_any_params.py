@@ -213,8 +213,13 @@ def test_keyswitch_any_base_any_size(tfhe, orc, n, N, t, gamma):
     K = _setup(tfhe, orc, n, N, 1, 2, 8, t=t, gamma=gamma)
     eng = K.ck.engine(0)
     u = _words(np.random.default_rng(n), 6, N + 1)
-    assert np.array_equal(eng.keyswitch(u), K.oracle.keyswitch(u))
+    got = eng.keyswitch(u)
+    assert np.array_equal(got, K.oracle.keyswitch(u))
     if n <= 64:
+        # ... and the integer restatement of keyswitch.jl:45-80 in tests/test_independent.py (no oracle)
+        from test_independent import Schoolbook
+        sb = Schoolbook(n, N, 1, 2, 8, t, gamma, K.ck.bootstrap_key, K.ck.keyswitch_key)
+        assert np.array_equal(got, np.stack([sb.keyswitch(row) for row in u]).astype(np.int32))
         _check_gates(tfhe, eng, K, f"keyswitch t = {t}, base {1 << gamma}")
     K.ck.close()
 

@@ -434,13 +434,13 @@ class MKSchoolbook(Schoolbook):
         return wrap32(res)
 
 
-def _mk_setup(tfhe, parties, l, beta, n, seed):
-    p = tfhe.SchemeParameters(n, 0.012467, 1024, 1, l, beta, 3.29e-10, 8, 2, 2.44e-5, parties)
+def _mk_setup(tfhe, parties, l, beta, n, seed, N=1024, t=8, gamma=2):
+    p = tfhe.SchemeParameters(n, 0.012467, N, 1, l, beta, 3.29e-10, t, gamma, 2.44e-5, parties)
     rng = np.random.default_rng(seed)
     sks = [tfhe.SecretKey(rng, p) for _ in range(parties)]
     shared = tfhe.SharedKey(rng, p)
     ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
-    sb = MKSchoolbook(n, 1024, l, beta, 8, 2, parties, ck.bootstrap_key, ck.keyswitch_key)
+    sb = MKSchoolbook(n, N, l, beta, t, gamma, parties, ck.bootstrap_key, ck.keyswitch_key)
     xs = tfhe.mk_encrypt(rng, sks, [True, False, True])
     ys = tfhe.mk_encrypt(rng, sks, [True, True, False])
     extra = rng.integers(-2**31, 2**31, size=(1, parties * n + 1), dtype=np.int64).astype(np.int32)     # an arbitrary word row
@@ -494,3 +494,32 @@ def test_gpu_mk_equals_schoolbook_full_size_2party(tfhe):
     assert np.array_equal(got[0], want)
     ck.close()
 
+
+
+# ---- multi-key sets outside the shipped shapes (round 5: the engine refuses none of them) -----------------------------------------
+MK_ANY_CASES = [  # parties, l, beta, n, N, t, gamma, kernel
+    (2, 4, 7, 3, 1024, 5, 3, "mk_blind_rotate_kernel_w2<4>"),                 # keyswitch t = 5 / base 8 (mk_internals.jl:397-411 takes any)
+    (2, 4, 7, 3, 512, 8, 2, "mk_blind_rotate_kernel_anyn(N=512,P=2,l=4)"),    # another polynomial degree
+    (9, 8, 4, 2, 1024, 8, 2, "mk_blind_rotate_kernel_anyn(N=1024,P=9,l=8)"),  # more parties than any shipped set
+]
+
+
+@pytest.mark.parametrize("parties,l,beta,n,N,t,gamma,kernel", MK_ANY_CASES)
+def test_oracle_mk_any_equals_schoolbook(orc, tfhe, parties, l, beta, n, N, t, gamma, kernel):
+    p, sks, ck, xs, ys, want = _mk_setup(tfhe, parties, l, beta, n, 700 + parties + N + t, N=N, t=t, gamma=gamma)
+    o = orc.Oracle(n, N, 1, l, beta, t, gamma, parties=parties)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    assert np.array_equal(o.mk_gate_nand(xs, ys, nthreads=4), want)
+    ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parties,l,beta,n,N,t,gamma,kernel", MK_ANY_CASES)
+def test_gpu_mk_any_equals_schoolbook(tfhe, parties, l, beta, n, N, t, gamma, kernel):
+    """tfhe_mk_gate_nand_batch on multi-key sets outside the shipped shapes against the multi-key schoolbook — no oracle."""
+    p, sks, ck, xs, ys, want = _mk_setup(tfhe, parties, l, beta, n, 700 + parties + N + t, N=N, t=t, gamma=gamma)
+    eng = ck.engine(0)
+    assert np.array_equal(eng.mk_gate_nand(xs, ys), want)
+    assert eng.last_kernel_name() == kernel, eng.last_kernel_name()
+    ck.close()
