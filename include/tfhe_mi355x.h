@@ -348,7 +348,7 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI v6): a caller that changes one for a while can put it back.  "br_anyn" (the any-N kernel
  * where a tuned one exists; like "ks_variant" it decides a key layout and must be chosen before the bootstrapping key is
- * loaded), "anyn_spec", "level_exchange" are new in v6. */
+ * loaded), "anyn_spec", "level_exchange", "k2_w3", "n512_rw", "n512_w2" (which N = 512 / k = 2 kernel a batch size takes) are new in v6. */
 int32_t tfhe_get_option(tfhe_ctx *ctx, const char *name, int64_t *value);
 
 #ifdef __cplusplus

@@ -97,6 +97,9 @@ def test_n512_tuned_kernel(tfhe, orc, l, beta):
     eng = K.ck.engine(0)
     x = _words(np.random.default_rng(512 + l), 6, 7)
     name = f"blind_rotate_kernel_n512<{l}>" if l in (2, 3) else f"blind_rotate_kernel_n512<0>(l={l})"
+    # the default for a batch this small: two waves per rotation (wave c owns polynomial c), up to six rotations per CU
+    _check_rotation(eng, K, x, name.replace("n512<", "n512w2<"), f"n512w2, l = {l}")
+    eng.set_option("n512_w2", 0)
     margin = _check_rotation(eng, K, x, name, f"n512, l = {l}")
     print(f"  rounding margin, N = 512 tuned kernel, l = {l}, beta = {beta}: {margin:.4f}")
     eng.set_option("n512_rw", 4)              # 6 rotations = one full group + one with two padding waves
@@ -104,6 +107,7 @@ def test_n512_tuned_kernel(tfhe, orc, l, beta):
     assert eng.last_kernel_name() == name.replace(">", ",rw4>", 1), eng.last_kernel_name()
     assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
     eng.set_option("n512_rw", 0)
+    eng.set_option("n512_w2", -1)
     e2 = tfhe.Engine(K.params, 0)
     e2.set_option("br_anyn", 1)
     e2.load_bootstrap_key(K.ck.bootstrap_key)
@@ -113,7 +117,7 @@ def test_n512_tuned_kernel(tfhe, orc, l, beta):
     e3 = tfhe.Engine(K.params, 0)
     e3.load_bootstrap_key_spectra(K.oracle.bk_spectra())
     assert np.array_equal(e3.bootstrap(MU, x, with_keyswitch=False), got)
-    assert e3.last_kernel_name() == name
+    assert e3.last_kernel_name() == name.replace("n512<", "n512w2<")
     e3.close()
     if l >= 2:
         _check_gates(tfhe, eng, K, f"n512, l = {l}")
@@ -441,7 +445,10 @@ def test_n512_full_size_set(tfhe, orc):
     bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
     ins = [tfhe.encrypt(K.rng, K.sk, v).data for v in bits]
     got = eng.gates(ops, *ins)
-    assert eng.last_kernel_name() == "blind_rotate_kernel_n512<2>"
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n512w2<2>", eng.last_kernel_name()      # ~1440 rotations: up to six per CU take two waves each
+    eng.set_option("n512_w2", 0)
+    assert np.array_equal(eng.gates(ops, *ins), got) and eng.last_kernel_name() == "blind_rotate_kernel_n512<2>"
+    eng.set_option("n512_w2", -1)
     x, y, z = bits
     want = np.select([sel == 0, sel == 1, sel == 2, sel == 3, sel == 4], [~(x & y), x & y, x | y, x ^ y, np.where(x, y, z)])
     assert np.array_equal(tfhe.decrypt(K.sk, got), want)

@@ -12,6 +12,8 @@ REPORT = os.path.join(ROOT, "tfhe.jl_amd", "build", "resource_usage.txt")
 # DIAG instantiations (rounding margin + in-kernel clock; run only under tfhe_set_option("measure_margin", 1)) that may
 # spill: the diagnostics add a live double and two 64-bit stamps to a kernel that is register-bound without them.
 DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 1>(MkBrArgs)",
+                  # (round 5: the fused rounding FMA keeps the rounding constant in two vector registers; 8 / 12 bytes in these two)
+                  "void blind_rotate_kernel_v3<0, 8, true, true, 4>(BrArgs)", "void blind_rotate_kernel_h2<3, true>(BrArgs, H2Tables)",
                   "void mk_blind_rotate_kernel_g2<4, 5, true, 2, true>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2, false>(MkGenArgs)"}
 # Non-DIAG instantiations that keep ONE or TWO spilled dwords (an LDS address reloaded once per CMUX step of 15 000 - 30 000
 # instructions) in the many-party two-wave kernel: every formulation tried without them was slower or spilled more
@@ -66,10 +68,10 @@ def test_blind_rotate_kernels_keep_two_waves_per_simd():
     #  value, L = 0: seven kernels that give EVERY unshipped l at k = 1, N = 1024 the speed of the tuned ones)
     #  round 5: + 7 for kernels_anyn.hpp — every parameter set outside N = 1024 / 2048, k <= 4, <= 8 parties: blind rotation
     #  single- / multi-key with their DIAG instantiations, key preparation, spectra permutation, RGSW.Expand)
-    assert len(rep) < 100, f"{len(rep)} kernels in the library"
+    assert len(rep) < 110, f"{len(rep)} kernels in the library"
     n512 = [k for k in rep if "blind_rotate_kernel_n512<" in k]      # three waves per SIMD is what the design is built on
-    assert len(n512) == 9 and all(rep[k]["scratch"] == 0 and rep[k]["occ"] >= 3 for k in n512), n512
+    assert len(n512) == 9 and len([k for k in rep if "blind_rotate_kernel_n512w2<" in k]) == 6 and all(rep[k]["scratch"] == 0 and rep[k]["occ"] >= 3 for k in n512), n512
     anyn = [k for k in rep if "anyn::" in k]
     assert len(anyn) == 7 and all(rep[k]["scratch"] == 0 for k in anyn), anyn
     rt = [k for k in rep if re.search(r"void blind_rotate_kernel_(v3|w2)<0,", k)]
-    assert len(rt) == 7 and all(rep[k]["scratch"] == 0 and rep[k]["occ"] >= 2 for k in rt), rt
+    assert len(rt) == 7 and all((rep[k]["scratch"] == 0 or k in DIAG_MAY_SPILL) and rep[k]["occ"] >= 2 for k in rt), rt

@@ -213,6 +213,19 @@ TFHE_HD int32_t round_to_torus32(double v)
 #endif
 }
 
+// the same of v * m in one FMA (one rounding instead of two before the integer is read off)
+TFHE_HD int32_t round_scaled_to_torus32(double v, double m)
+{
+    const double t = __builtin_fma(v, m, 6755399441055744.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int32_t)__double2loint(t);
+#else
+    uint64_t u;
+    memcpy(&u, &t, 8);
+    return (int32_t)(uint32_t)u;
+#endif
+}
+
 // Gadget decomposition constants (tgsw.jl:8-21, 99-117).
 struct Gadget {
     int32_t offset;     // sum_p 2^(32 - p beta) * 2^(beta-1), wrapped
@@ -326,6 +339,19 @@ TFHE_HD constexpr double tws(int r)
          : r == 6 ? 0.92387953251128675613 : 0.98078528040323044913;
 }
 
+// The register part of the twist in "tan form": e^{-i pi r/16} = twk(r) (1 - i twt(r)) for r <= 4 and, through
+// e^{-i pi r/16} = -i e^{+i pi (8 - r)/16}, = twk(r) (twt(r) - i) for r > 4, with twt(r) = tan(pi min(r, 8 - r)/16) and
+// twk(r) = cos(pi min(r, 8 - r)/16): two FMAs per point instead of a multiply and an FMA per component, and only three
+// tangents and four cosines as constants (they live in scalar registers).  The cosine left behind rides on the FMAs of the
+// butterfly that follows (dft8_fwd_tw) or on the FMA that adds the rounding constant (untwist_add2).
+TFHE_HD constexpr double twt(int r)
+{
+    return (r == 1 || r == 7) ? 0.19891236737965800691 : (r == 2 || r == 6) ? 0.41421356237309504880
+         : (r == 3 || r == 5) ? 0.66817863791929891999 : r == 4 ? 1.0 : 0.0;
+}
+TFHE_HD constexpr double twk(int r) { return twc(r < 4 ? r : 8 - r); }
+TFHE_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // xor mask that turns every beta-bit digit field into its signed (two's complement) form
 TFHE_HD int32_t gadget_xor_mask(int l, int log2_base)
 {
@@ -423,6 +449,49 @@ TFHE_HD void load_digits2(const int32_t (&temp)[16], int p, int log2_base, cplx 
         else x[r] = mk(lo * twc(r) - hi * tws(r), -(lo * tws(r) + hi * twc(r)));
     }
 }
+// tan form of one point: (a - i b) e^{-i pi r/16} / twk(r)
+template <int R>
+TFHE_HD cplx twist_tan(double a, double b)
+{
+    if (R == 0) return mk(a, -b);
+    if (R == 4) return mk(a - b, -(b + a));
+    if (R < 4) return mk(fma_(-twt(R), b, a), -fma_(twt(R), a, b));
+    return mk(fma_(twt(R), a, -b), -fma_(twt(R), b, a));
+}
+// u[r] = load_digits2's x[r] / twk(r): 12 FMAs and 2 additions instead of 28 operations
+TFHE_HD void load_digits2t(const int32_t (&temp)[16], int p, int log2_base, cplx (&u)[8])
+{
+#define TFHE_TW_(R) u[R] = twist_tan<R>((double)digit2(temp[R], p, log2_base), (double)digit2(temp[R + 8], p, log2_base))
+    TFHE_TW_(0); TFHE_TW_(1); TFHE_TW_(2); TFHE_TW_(3); TFHE_TW_(4); TFHE_TW_(5); TFHE_TW_(6); TFHE_TW_(7);
+#undef TFHE_TW_
+}
+// dft8<false> of x[r] = twk(r) u[r]: the cosines ride on the butterfly's additions as FMA multipliers (the ratio of the
+// cosines of the two operands; what is left over at the outputs is twk(0) = 1).  50 operations (dft8: 52).
+constexpr double kTwR0 = 0.70710678118654752440;      // twk(4) / twk(0)
+constexpr double kTwR1 = 0.84775906502257351226;      // twk(5) / twk(1) = c3 / c1   (twk(6) / twk(2) = 1)
+constexpr double kTwR3 = 1.1795804271032745923;       // twk(7) / twk(3) = c1 / c3
+constexpr double kTwG0 = 0.92387953251128675613;      // twk(2) / twk(0)            (twk(3) / twk(1) = kTwR1)
+constexpr double kTwL = 0.98078528040323044913;       // twk(1) / twk(0)
+constexpr double kTwSL = 0.69351992266107373091;      // that / sqrt(2)
+TFHE_HD cplx axpy(cplx a, double m, cplx b) { return mk(fma_(m, b.x, a.x), fma_(m, b.y, a.y)); }      // a + m b
+TFHE_HD void dft8_fwd_tw(cplx (&x)[8])
+{
+    const cplx a0 = axpy(x[0], kTwR0, x[4]), a1 = axpy(x[1], kTwR1, x[5]), a2 = cadd(x[2], x[6]), a3 = axpy(x[3], kTwR3, x[7]);
+    const cplx t0 = axpy(x[0], -kTwR0, x[4]), t1 = axpy(x[1], -kTwR1, x[5]), t2 = csub(x[2], x[6]), t3 = axpy(x[3], -kTwR3, x[7]);
+    const cplx b1 = mk(t1.x + t1.y, t1.y - t1.x);     // t1 * (1 - i)        (scale c1, lacks 1/sqrt(2))
+    const cplx b2 = mk(t2.y, -t2.x);                  // t2 * (-i)           (scale c2)
+    const cplx b3 = mk(t3.y - t3.x, -(t3.x + t3.y));  // t3 * (-1 - i)       (scale c3, lacks 1/sqrt(2))
+    {
+        const cplx c0 = axpy(a0, kTwG0, a2), d0 = axpy(a0, -kTwG0, a2), c1 = axpy(a1, kTwR1, a3), e = axpy(a1, -kTwR1, a3);
+        const cplx d1 = mk(e.y, -e.x);
+        x[0] = axpy(c0, kTwL, c1); x[4] = axpy(c0, -kTwL, c1); x[2] = axpy(d0, kTwL, d1); x[6] = axpy(d0, -kTwL, d1);
+    }
+    {
+        const cplx c0 = axpy(t0, kTwG0, b2), d0 = axpy(t0, -kTwG0, b2), c1 = axpy(b1, kTwR1, b3), e = axpy(b1, -kTwR1, b3);
+        const cplx d1 = mk(e.y, -e.x);
+        x[1] = axpy(c0, kTwSL, c1); x[5] = axpy(c0, -kTwSL, c1); x[3] = axpy(d0, kTwSL, d1); x[7] = axpy(d0, -kTwSL, d1);
+    }
+}
 TFHE_HD void fwd2_pass_a(cplx (&x)[8], const LaneTw &w)
 {
     dft8<false>(x);
@@ -457,21 +526,39 @@ TFHE_HD double frac_dist(double v)
 
 // conj(y) * e^{-i pi r/16}: real -> coefficient t+64r, imag -> t+64r+512; round, add into acc.
 // MARGIN: also track the largest distance of a pre-round value from an integer (must stay << 0.5).
-template <bool MARGIN = false>
+// FUSED = false: the cosine as a multiplication of its own (a kernel with no two registers to spare for the rounding constant,
+// which the fused form needs in vector registers: the FMA's other constant already takes the one scalar operand)
+template <bool MARGIN = false, bool FUSED = true>
 TFHE_HD void untwist_add2(const cplx (&y)[8], int32_t (&acc)[16], double *worst = nullptr)
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        double re, im;
-        if (r == 0) { re = y[r].x; im = -y[r].y; }
-        else { re = y[r].x * twc(r) - y[r].y * tws(r); im = -(y[r].x * tws(r) + y[r].y * twc(r)); }
-        if (MARGIN) {
-            const double a = frac_dist(re), b = frac_dist(im);
-            if (a > *worst) *worst = a;
-            if (b > *worst) *worst = b;
+        if (FUSED) {
+            // tan form (twist_tan of conj(y) = y.x - i y.y): the cosine rides on the FMA that adds the rounding constant
+            double zr, zi;
+            if (r == 0) { zr = y[r].x; zi = y[r].y; }
+            else if (r == 4) { zr = y[r].x - y[r].y; zi = y[r].y + y[r].x; }
+            else if (r < 4) { zr = fma_(-twt(r), y[r].y, y[r].x); zi = fma_(twt(r), y[r].x, y[r].y); }
+            else { zr = fma_(twt(r), y[r].x, -y[r].y); zi = fma_(twt(r), y[r].y, y[r].x); }
+            if (MARGIN) {
+                const double a = frac_dist(zr * twk(r)), b = frac_dist(zi * twk(r));
+                if (a > *worst) *worst = a;
+                if (b > *worst) *worst = b;
+            }
+            acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_scaled_to_torus32(zr, twk(r)));
+            acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_scaled_to_torus32(zi, -twk(r)));
+        } else {
+            double re, im;
+            if (r == 0) { re = y[r].x; im = -y[r].y; }
+            else { re = y[r].x * twc(r) - y[r].y * tws(r); im = -(y[r].x * tws(r) + y[r].y * twc(r)); }
+            if (MARGIN) {
+                const double a = frac_dist(re), b = frac_dist(im);
+                if (a > *worst) *worst = a;
+                if (b > *worst) *worst = b;
+            }
+            acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
+            acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(im));
         }
-        acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
-        acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(im));
     }
 }
 

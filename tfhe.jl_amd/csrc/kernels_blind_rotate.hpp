@@ -163,12 +163,12 @@ __device__ __forceinline__ void rotate_poly(int lane, int a, const int32_t *img,
 #endif
 }
 // acc += round(untwisted y), image updated in place (mirror included)
-template <bool MARGIN>
+template <bool MARGIN, bool FUSED = true>
 __device__ __forceinline__ void accumulate_poly(int lane, const cplx (&y)[8], int32_t *img, double *worst)
 {
     int32_t accr[16];
     load_cur<16>(lane, img, accr);
-    untwist_add2<MARGIN>(y, accr, worst);
+    untwist_add2<MARGIN, FUSED>(y, accr, worst);
     store_cur<16>(lane, accr, img);
 }
 // accum = (0, ..., 0, X^{-barb} * (mu, ..., mu))     bootstrap.jl:54-56,78 ; tlwe.jl:77-81
@@ -297,9 +297,14 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
             const int c = L ? f / (L ? L : 1) : (f >= Lr), p = L ? f % (L ? L : 1) : f - c * Lr;        // component, digit index (0-based)
             if (p == 0) rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
             cplx x[8];
+#ifdef TFHE_NO_TANFORM       // A/B builds only: the twist as multiply + FMA per component
             load_digits2(temp, p + 1, beta, x);
-            // pass A
             dft8<false>(x);
+#else
+            load_digits2t(temp, p + 1, beta, x);
+            dft8_fwd_tw(x);
+#endif
+            // pass A
 #pragma unroll
             for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
 #ifndef TFHE_ABL_X1
@@ -453,10 +458,11 @@ struct MkBrArgs {
 
 // `mid()` runs between the store and the load of the second transposition, when x[] is dead: the place to request global
 // data (32 registers are free there) that the caller needs right after the transform.
-template <typename MID>
+// TW: x[] comes from load_digits2t (the register part of the twist in tan form; its cosines ride on the first butterfly)
+template <bool TW = false, typename MID>
 __device__ __forceinline__ void fft_fwd_wave_mid(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch, MID &&mid)
 {
-    dft8<false>(x);
+    if (TW) dft8_fwd_tw(x); else dft8<false>(x);
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
     x1_store_a(lane, x, xch);
@@ -475,9 +481,10 @@ __device__ __forceinline__ void fft_fwd_wave_mid(int lane, cplx (&x)[8], const c
     dft8<false>(x);
 }
 
+template <bool TW = false>
 __device__ __forceinline__ void fft_fwd_wave(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
 {
-    dft8<false>(x);
+    if (TW) dft8_fwd_tw(x); else dft8<false>(x);
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
     x1_store_a(lane, x, xch);
@@ -636,7 +643,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
         STAMP(6);
         auto finish = [&](cplx (&o)[8], int d) {
             fft_inv_wave(lane, o, tw1f, tw2_lds, xch_oth);
-            accumulate_poly<MARGIN>(lane, o, acc_lds + d * kImg, &worst);
+            accumulate_poly<MARGIN, false>(lane, o, acc_lds + d * kImg, &worst);
         };
         if (WV == 0) { finish(out[0], 0); finish(out[1], 1); }
         else finish(out[NP], NP);
@@ -915,7 +922,7 @@ __device__ __forceinline__ void g2_party_steps(const MkGenArgs &P, const int32_t
                 }
                 if constexpr (has_self) {      // a'_s complete: only source s feeds it, only this wave read acc[s] in this step
                     fft_inv_wave(lane, o_self, tw1f, tw2_lds, xch_own);
-                    accumulate_poly<MARGIN>(lane, o_self, acc + s * kImg, &worst);
+                    accumulate_poly<MARGIN, false>(lane, o_self, acc + s * kImg, &worst);
                 }
             }
         });
@@ -935,13 +942,13 @@ __device__ __forceinline__ void g2_party_steps(const MkGenArgs &P, const int32_t
             for (int k2 = 0; k2 < 8; k2++) o_party[k2] = cadd(o_party[k2], xch_oth[k2 * 64 + lane]);
             WAVE_LDS_FENCE();
             fft_inv_wave(lane, o_party, tw1f, tw2_lds, xch_oth);
-            accumulate_poly<MARGIN>(lane, o_party, acc + PARTY * kImg, &worst);
+            accumulate_poly<MARGIN, false>(lane, o_party, acc + PARTY * kImg, &worst);
         } else {
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) o_body[k2] = cadd(o_body[k2], xch_oth[k2 * 64 + lane]);
             WAVE_LDS_FENCE();
             fft_inv_wave(lane, o_body, tw1f, tw2_lds, xch_oth);
-            accumulate_poly<MARGIN>(lane, o_body, acc + NP * kImg, &worst);
+            accumulate_poly<MARGIN, false>(lane, o_body, acc + NP * kImg, &worst);
         }
         // accumulator stores of this step visible to the other wave of the rotation; also ends the use of the LDS hand-off
         // (ACCL: the accumulators are in LDS and the barrier alone orders them)
@@ -1078,12 +1085,12 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_w2(BrArgs P)
         auto digit = [&](int p, auto first_c) {
             constexpr bool FIRST = decltype(first_c)::value;
             cplx x[8];
-            load_digits2(temp, p + 1, beta, x);
+            load_digits2t(temp, p + 1, beta, x);
             const cplx *kp = key + (size_t)p * K1 * K1 * kM;
             cplx kown[8];
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) kown[k2] = kp[(size_t)wv * kM + k2 * 64];           // co = wv (issued before the FFT)
-            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            fft_fwd_wave<true>(lane, x, tw1f, tw2_lds, xch);
             STAMP(1);
             cplx koth[8];
 #pragma unroll
@@ -1154,9 +1161,19 @@ __device__ __forceinline__ void dft4(cplx (&x)[4])
 
 struct H2LaneTw { cplx tw1[4], tw2[4], tw3[4]; };
 
-__device__ __forceinline__ void fft256_fwd(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb)
+// dft4<false> of x[r] = S_r x'[r] with S = (1, s1, c2, s1 c3 / c1), c_r = cos(pi r/16): what blind_rotate_kernel_h2's first stage
+// leaves when the register part of the twist is applied in tan form (load_digits2t); the scales ride on the additions as FMAs
+__device__ __forceinline__ void dft4_fwd_scaled(cplx (&x)[4], double s1)
 {
-    dft4<false>(x);
+    const cplx a = axpy(x[0], kTwG0, x[2]), b = axpy(x[0], -kTwG0, x[2]), c = axpy(x[1], kTwR1, x[3]), d = axpy(x[1], -kTwR1, x[3]);
+    const cplx id = mk(d.y, -d.x);
+    x[0] = axpy(a, s1, c); x[2] = axpy(a, -s1, c); x[1] = axpy(b, s1, id); x[3] = axpy(b, -s1, id);
+}
+
+template <bool SCALED = false>
+__device__ __forceinline__ void fft256_fwd(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb, double s1 = 1.0)
+{
+    if (SCALED) dft4_fwd_scaled(x, s1); else dft4<false>(x);
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = cmul(x[q], w.tw1[q]);
 #pragma unroll
@@ -1237,16 +1254,21 @@ __device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], con
         else kb = mk(-(be.x + be.y) * rs, (be.x - be.y) * rs);
         const cplx wq = H ? csub(al, kb) : cadd(al, kb);
         constexpr int R8 = R + 4 * H;
-        const double re = wq.x * twc(R8) - wq.y * tws(R8), im = wq.x * tws(R8) + wq.y * twc(R8);           // conj(c_R8)
+        // g = wq conj(c_R8), tan form (br_core.hpp, twist_tan): the cosine rides on the rounding FMA
+        double zr, zi;
+        if (R8 == 0) { zr = wq.x; zi = wq.y; }
+        else if (R8 == 4) { zr = wq.x - wq.y; zi = wq.y + wq.x; }
+        else if (R8 < 4) { zr = fma_(-twt(R8), wq.y, wq.x); zi = fma_(twt(R8), wq.x, wq.y); }
+        else { zr = fma_(twt(R8), wq.x, -wq.y); zi = fma_(twt(R8), wq.y, wq.x); }
         if (MARGIN) {
-            const double fa = frac_dist(re), fb = frac_dist(im);
+            const double fa = frac_dist(zr * twk(R8)), fb = frac_dist(zi * twk(R8));
             worst = fa > worst ? fa : worst;
             worst = fb > worst ? fb : worst;
         }
         const int jlo = lane + 64 * R8;
         const int32_t clo = cur[R8], chi = cur[R8 + 8];     // read at rotate time; nobody else writes them
-        const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_to_torus32(re));
-        const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_to_torus32(-im));
+        const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_scaled_to_torus32(zr, twk(R8)));
+        const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_scaled_to_torus32(zi, -twk(R8)));
         acc_lds[kMir + jlo] = nlo;
         acc_lds[kMir + jlo + kM] = nhi;
         if (H == 1 && R == 3) acc_lds[lane] = (int32_t)(0u - (uint32_t)nhi);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
@@ -1285,7 +1307,6 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     const int32_t *bara = P.bara + w * (P.n + 1);
     const int beta = P.g.log2_base;
     const int32_t xormask = gadget_xor_mask(L, beta);
-    const double rs = 0.70710678118654752440;
 
     H2LaneTw tw;
 #pragma unroll
@@ -1321,21 +1342,23 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
             load_cur<16>(lane, acc_lds, cur);
             rotate_sub3<16>(lane, __builtin_amdgcn_readfirstlane(a), acc_lds, cur, P.g.offset, xormask, temp);
             STAMP(0);
-            cplx x8[8];
-            load_digits2(temp, p + 1, beta, x8);      // (d[t+64r] - i d[t+64r+512]) e^{-i pi r/16}, r < 8
+            // z_r = (d[t+64r] - i d[t+64r+512]) e^{-i pi r/16} = c_r u_r, r < 8 (tan form: load_digits2t); the half's input is
+            // z_r + z_{r+4} (h = 0) or (z_r - z_{r+4}) kappa^r, kappa = e^{-i pi/4} (h = 1) = c_r (u_r +- (c_{r+4} / c_r) u_{r+4}) [kappa^r]:
+            // the c_r and kappa's 1/sqrt(2) ride on the first butterfly of the transform (dft4_fwd_scaled)
+            cplx u[8];
+            load_digits2t(temp, p + 1, beta, u);
             if (h == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) x[r] = cadd(x8[r], x8[r + 4]);
-            } else {                                   // (z_r - z_{r+4}) kappa^r, kappa = e^{-i pi/4}
-                const cplx d0 = csub(x8[0], x8[4]), d1 = csub(x8[1], x8[5]), d2 = csub(x8[2], x8[6]), d3 = csub(x8[3], x8[7]);
-                x[0] = d0;
-                x[1] = mk((d1.x + d1.y) * rs, (d1.y - d1.x) * rs);
+                x[0] = axpy(u[0], kTwR0, u[4]); x[1] = axpy(u[1], kTwR1, u[5]); x[2] = cadd(u[2], u[6]); x[3] = axpy(u[3], kTwR3, u[7]);
+            } else {
+                const cplx d1 = axpy(u[1], -kTwR1, u[5]), d2 = csub(u[2], u[6]), d3 = axpy(u[3], -kTwR3, u[7]);
+                x[0] = axpy(u[0], -kTwR0, u[4]);
+                x[1] = mk(d1.x + d1.y, d1.y - d1.x);
                 x[2] = mk(d2.y, -d2.x);
-                x[3] = mk((d3.y - d3.x) * rs, -(d3.x + d3.y) * rs);
+                x[3] = mk(d3.y - d3.x, -(d3.x + d3.y));
             }
         }
         STAMP(1);
-        fft256_fwd(lane, x, tw, tb);
+        fft256_fwd<true>(lane, x, tw, tb, h ? kTwSL : kTwL);      // c1 / sqrt(2) : c1
         STAMP(2);
         cplx own[4], oth[4];                     // this wave's contribution to output component c / 1 - c (half h)
 #pragma unroll
@@ -1480,8 +1503,8 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_k2(BrArgs P)
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) kfirst[k2] = kp[k2 * 64];
                 cplx x[8];
-                load_digits2(temp, p + 1, beta, x);
-                fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+                load_digits2t(temp, p + 1, beta, x);
+                fft_fwd_wave<true>(lane, x, tw1f, tw2_lds, xch);
 #pragma unroll
                 for (int co = 0; co < K1; co++) {
                     cplx kv[8];
@@ -1577,12 +1600,12 @@ __global__ __launch_bounds__(192, 2) void blind_rotate_kernel_k2w3(BrArgs P)
         auto digit = [&](int p, auto first_c) {
             constexpr bool FIRST = decltype(first_c)::value;
             cplx x[8];
-            load_digits2(temp, p + 1, beta, x);
+            load_digits2t(temp, p + 1, beta, x);
             const cplx *kp = key + (size_t)p * K1 * K1 * kM;
             cplx kv[8];
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) kv[k2] = kp[(size_t)wv * kM + k2 * 64];             // co = wv (issued before the FFT)
-            fft_fwd_wave(lane, x, tw1f, tw2_lds, xch);
+            fft_fwd_wave<true>(lane, x, tw1f, tw2_lds, xch);
 #pragma unroll
             for (int k2 = 0; k2 < 8; k2++) own[k2] = FIRST ? cmul(x[k2], kv[k2]) : cfma(x[k2], kv[k2], own[k2]);
 #pragma unroll

@@ -214,3 +214,109 @@ __global__ __launch_bounds__(64) void bk_permute_c128_kernel_n512(const cplx *__
         out[q * kM5 + q4 * 64 + lane] = mk(v.x * s, v.y * s);
     }
 }
+
+// ---- N = 512, small and medium batches: TWO waves per rotation (blind_rotate_kernel_w2's structure at this degree) ------------------
+// One wave per rotation leaves a CU's SIMDs idle below 12 rotations per CU and makes a single gate 500 x (4 forward + 2 inverse
+// transforms) of one wave's latency long (1.96 ms — longer than a single N = 1024 gate on blind_rotate_kernel_h2).  Here wave c owns
+// accumulator polynomial c: it rotates and decomposes only its own polynomial, runs its L forward transforms, multiplies into
+// partial sums of both output components, hands the other component's over through its transposition buffer (the two buffers
+// change hands every step: ONE barrier per step), adds what it receives, inverse-transforms its own component and updates its
+// own polynomial.  14.8 KB of LDS per rotation.
+constexpr int kN512W2LdsBytes = 2 * kImg5 * 4 + 2 * kH2Buf * (int)sizeof(cplx);      // per rotation
+template <int L, bool MARGIN = false>
+__global__ __launch_bounds__(128, 3) void blind_rotate_kernel_n512w2(N512Args P)
+{
+    constexpr int K1 = 2;
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    diag_begin<MARGIN>(dg_t0, dg_r0);
+    double worst = 0.0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg5]
+    cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kImg5 * 4);              // [2][kH2Buf]: the waves swap them every step
+    const int wv = wave_in_block();                                              // wave = owned polynomial
+    const int lane = (int)threadIdx.x & 63;
+    int32_t *acc_lds = acc_all + wv * kImg5;
+    const size_t w = blockIdx.x;
+    const int32_t *bara = P.bara + w * (P.n + 1);
+    const int beta = P.g.log2_base;
+    const int Lr = L ? L : P.l;
+    const int32_t xormask = gadget_xor_mask(Lr, beta);
+
+    H2LaneTw tw;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        tw.tw1[q] = P.tw1[q * 64 + lane];
+        tw.tw2[q] = P.tw2q[q * 16 + (lane & 15)];
+        tw.tw3[q] = P.tw3q[q * 4 + (lane & 3)];
+    }
+    {
+        const int barb = bara[P.n] & (2 * kN5 - 1);
+        int32_t v[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int idx = (lane + 64 * m + barb) & (2 * kN5 - 1);
+            v[m] = wv == 0 ? 0 : (idx & kN5) ? (int32_t)(0u - (uint32_t)P.mu) : P.mu;
+        }
+        store_cur<8>(lane, v, acc_lds);
+    }
+    __syncthreads();
+
+    int a_next = load_uniform_i32(bara) & (2 * kN5 - 1);
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {
+        const int a = a_next;
+        a_next = load_uniform_i32(bara + i + 1) & (2 * kN5 - 1);
+        // key polys of transform (p, c = wv): [i][p][c][co][4][64]
+        const cplx *key = P.bk + (size_t)i * (Lr * K1 * K1 * kM5) + (size_t)wv * K1 * kM5 + lane;
+        // in step i this wave transforms in buffer (wv ^ i) & 1 and leaves its hand-off there; after the barrier it reads the other
+        // wave's hand-off from the other buffer, runs its inverse transform in it and keeps it for the next step's forward transforms
+        cplx *tb = tb_all + ((wv ^ i) & 1) * kH2Buf, *tb_next = tb_all + ((wv ^ i ^ 1) & 1) * kH2Buf;
+        cplx own[4], oth[4];
+        int32_t temp[8];
+        rotate_poly<8>(lane, a, acc_lds, P.g.offset, xormask, temp);
+#pragma unroll 1
+        for (int p = 0; p < Lr; p++) {
+            const cplx *kp = key + (size_t)p * K1 * K1 * kM5;
+            cplx kown[4], koth[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) { kown[q4] = kp[(size_t)wv * kM5 + q4 * 64]; koth[q4] = kp[(size_t)(1 - wv) * kM5 + q4 * 64]; }
+            cplx x[4];
+            load_digits4(temp, p + 1, beta, x);
+            fft256_fwd(lane, x, tw, tb);
+            if (p == 0) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) { own[q4] = cmul(x[q4], kown[q4]); oth[q4] = cmul(x[q4], koth[q4]); }
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) { own[q4] = cfma(x[q4], kown[q4], own[q4]); oth[q4] = cfma(x[q4], koth[q4], oth[q4]); }
+            }
+        }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) tb[q4 * 64 + lane] = oth[q4];
+        __syncthreads();
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) own[q4] = cadd(own[q4], tb_next[q4 * 64 + lane]);
+        WAVE_LDS_FENCE();
+        fft256_inv(lane, own, tw, tb_next);
+        int32_t accr[8];
+        load_cur<8>(lane, acc_lds, accr);
+        untwist_add4<MARGIN>(own, accr, worst);
+        store_cur<8>(lane, accr, acc_lds);
+        WAVE_LDS_FENCE();
+    }
+    __syncthreads();
+    diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
+    int32_t *ext = P.ext + w * (kN5 + 1);
+    if (wv == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int j = lane + 64 * m;
+            const int32_t v = acc_all[kMir + j];
+            if (j == 0) ext[0] = v;
+            else ext[kN5 - j] = (int32_t)(0u - (uint32_t)v);
+        }
+    } else if (lane == 0) {
+        ext[kN5] = acc_all[kImg5 + kMir];
+    }
+}

@@ -188,6 +188,7 @@ struct tfhe_ctx {
     std::vector<int32_t> kid_tickets[2];  // multi-device context: per submit slot, the ticket every kid gave for its shard (2: none)
     int cu_count = 256;          // compute units of the device (hipDeviceAttributeMultiprocessorCount)
     int w2_rw = 0;               // tfhe_set_option("w2_rw", 0 | 1 | 2): rotations per workgroup of the two-wave kernel; 0 = pairs up to two rotations per CU and at (nearly) four
+    int n512_w2 = -1;            // tfhe_set_option("n512_w2", -1 | 0 | 1): the two-waves-per-rotation N = 512 kernel up to 6 rotations per CU (-1), never, always
     int n512_rw = 0;             // tfhe_set_option("n512_rw", 0 | 1 | 4): rotations per workgroup of the N = 512 kernel (0: by batch size)
     int k2_w3 = -1;              // tfhe_set_option("k2_w3", -1 | 0 | 1): the three-waves-per-rotation k = 2 kernel for batches of up to two rotations per CU and for the last round of a larger one (-1: by size), never (0), for every batch (1)
     int k2_rw = 0;               // tfhe_set_option("k2_rw", 0 | 1 | 7): rotations per workgroup of the k = 2 kernel; 0 = equally full rounds of up to seven per CU
@@ -969,7 +970,22 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.g = c->g; b.n = a.n; b.mu = mu; b.R = (int32_t)R; b.l = L;
         b.prio_steps = a.prio_steps;
         b.tw1 = c->d_tables + kN512TableOffset; b.tw2q = c->d_tables + kH2TableOffset + 512; b.tw3q = b.tw2q + 64;
-        const bool group = !dg && (c->n512_rw == 4 || (c->n512_rw == 0 && R >= 12 * (size_t)c->cu_count));
+        // two waves per rotation (wave c owns polynomial c) while the batch leaves SIMDs idle on the one-wave kernel: option
+        // "n512_w2" (-1: up to 6 rotations per CU, 0: never, 1: always).  One device, tfhe_parameters_80 with N = 512
+        // (profiles/r05/r05k_n512_timing.txt): 1 rotation 1.13 vs 1.98 ms, 1024: 1.94 vs 2.58, 1536: 2.71 vs 2.96, 2048: 3.92 vs 3.44
+        if (c->n512_w2 == 1 || (c->n512_w2 < 0 && R <= 6 * (size_t)c->cu_count)) {
+            const size_t ldsw = kN512W2LdsBytes;
+#define LAUNCH_N512W2(LL)                                                                                          \
+            if (dg) hipLaunchKernelGGL((blind_rotate_kernel_n512w2<LL, true>), dim3((unsigned)R), dim3(128), ldsw, s, b);        \
+            else hipLaunchKernelGGL((blind_rotate_kernel_n512w2<LL, false>), dim3((unsigned)R), dim3(128), ldsw, s, b)
+            BR_CASES_ANY_L(LAUNCH_N512W2)
+#undef LAUNCH_N512W2
+            HIP_TRY(c, hipGetLastError());
+            if ((L == 2 || L == 3) && !c->br_rt_l) name_kernel(c, "blind_rotate_kernel_n512w2<%d>", L);
+            else name_kernel(c, "blind_rotate_kernel_n512w2<0>(l=%d)", L);
+            return TFHE_OK;
+        }
+        const bool group = !dg && (c->n512_rw == 4 || (c->n512_rw == 0 && R >= 8 * (size_t)c->cu_count));      // (2048 rotations: 3.44 vs 3.82 ms, 3072: 4.68 vs 5.11)
         const size_t lds5 = (size_t)(group ? 4 : 1) * kN512LdsBytes;
 #define LAUNCH_N512(LL)                                                                                            \
         if (dg) hipLaunchKernelGGL((blind_rotate_kernel_n512<LL, true, 1>), dim3((unsigned)R), dim3(64), lds5, s, b);            \
@@ -1820,7 +1836,7 @@ static int32_t ensure_twin(tfhe_ctx *c)
     t->d_ks4 = c->d_ks4; t->ks4_wtiles = c->ks4_wtiles; t->ks_mode = c->ks_mode; t->have_bk = c->have_bk; t->have_ks = c->have_ks;
     t->ks_slices_large = c->ks_slices_large; t->ks_variant = c->ks_variant; t->br_small = c->br_small; t->br_prio_pct = c->br_prio_pct;
     t->br_tiny = c->br_tiny; t->br_rt_l = c->br_rt_l; t->timing_events = c->timing_events; t->br_split = c->br_split; t->br_general = c->br_general; t->n2048_rw = c->n2048_rw; t->v3_rw = c->v3_rw; t->k2_rw = c->k2_rw; t->w2_rw = c->w2_rw;
-    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3; t->n512_rw = c->n512_rw;
+    t->br_anyn = c->br_anyn; t->anyn_spec = c->anyn_spec; t->k2_w3 = c->k2_w3; t->n512_rw = c->n512_rw; t->n512_w2 = c->n512_w2;
     return TFHE_OK;
 }
 
@@ -2785,7 +2801,7 @@ int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value)
         {"br_small", c->br_small}, {"br_tiny", c->br_tiny}, {"br_rt_l", c->br_rt_l}, {"timing_events", c->timing_events},
         {"br_split", c->br_split}, {"br_general", c->br_general}, {"br_anyn", c->br_anyn}, {"anyn_spec", c->anyn_spec},
         {"level_split_min", c->level_split_min}, {"level_exchange", c->level_exchange}, {"br_prio_pct", c->br_prio_pct}, {"ks_slices", c->ks_slices_large},
-        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3}, {"n512_rw", c->n512_rw},
+        {"measure_margin", c->measure_margin ? 1 : 0}, {"pipeline_min", c->pipeline_min}, {"w2_rw", c->w2_rw}, {"k2_rw", c->k2_rw}, {"k2_w3", c->k2_w3}, {"n512_rw", c->n512_rw}, {"n512_w2", c->n512_w2},
         {"v3_rw", c->v3_rw}, {"mk_general", c->mk_force_general ? 1 : 0}, {"n2048_rw", c->n2048_rw}, {"mkg_acc", c->mkg_acc},
         {"mkg_variant", c->mkg_variant}, {"mkg_rw", c->mkg_rw}, {"mk_rw", c->mk_rw}, {"ks_variant", c->ks_variant},
     };
@@ -2846,6 +2862,11 @@ int32_t tfhe_set_option(tfhe_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "w2_rw")) {
         if (value < 0 || value > 2) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: w2_rw must be 0 (by batch size), 1 or 2");
         c->w2_rw = (int)value;
+        return TFHE_OK;
+    }
+    if (!strcmp(name, "n512_w2")) {
+        if (value < -1 || value > 1) return c->set_err(TFHE_ERR_INVALID_ARG, "set_option: n512_w2 must be -1 (by batch size), 0 (never) or 1 (always)");
+        c->n512_w2 = (int)value;
         return TFHE_OK;
     }
     if (!strcmp(name, "n512_rw")) {

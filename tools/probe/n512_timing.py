@@ -8,11 +8,12 @@ rng = np.random.default_rng(1)
 sk, ck = tfhe.make_key_pair(rng, p, keygen="device")
 eng = ck.engine(0)
 eng.set_option("pipeline_min", -1)
-for g in (1, 256, 1024, 3072, 4096, 8192, 16384):
+for g in (1, 256, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192):
     x = rng.integers(-2**31, 2**31, size=(g, 501), dtype=np.int64).astype(np.int32)
     row = {}
-    for rw in (1, 4):
-        eng.set_option("n512_rw", rw)
+    for rw in (1, 4, 2):
+        eng.set_option("n512_w2", 1 if rw == 2 else 0)
+        eng.set_option("n512_rw", rw if rw != 2 else 0)
         t = []
         for _ in range(5):
             eng.bootstrap(2**29, x, with_keyswitch=False)
