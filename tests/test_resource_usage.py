@@ -12,8 +12,8 @@ REPORT = os.path.join(ROOT, "tfhe.jl_amd", "build", "resource_usage.txt")
 # DIAG instantiations (rounding margin + in-kernel clock; run only under tfhe_set_option("measure_margin", 1)) that may
 # spill: the diagnostics add a live double and two 64-bit stamps to a kernel that is register-bound without them.
 DIAG_MAY_SPILL = {"void mk_blind_rotate_kernel_w2<4, true, 1>(MkBrArgs)",
-                  # (round 5: the fused rounding FMA keeps the rounding constant in two vector registers; 8 / 12 bytes in these two)
-                  "void blind_rotate_kernel_v3<0, 8, true, true, 4>(BrArgs)", "void blind_rotate_kernel_h2<3, true>(BrArgs, H2Tables)",
+                  # (round 5: the fused rounding FMA keeps the rounding constant in two vector registers; 8 bytes here)
+                  "void blind_rotate_kernel_v3<0, 8, true, true, 4>(BrArgs)",
                   "void mk_blind_rotate_kernel_g2<4, 5, true, 2, true>(MkGenArgs)", "void mk_blind_rotate_kernel_g2<8, 8, true, 2, false>(MkGenArgs)"}
 # Non-DIAG instantiations that keep ONE or TWO spilled dwords (an LDS address reloaded once per CMUX step of 15 000 - 30 000
 # instructions) in the many-party two-wave kernel: every formulation tried without them was slower or spilled more

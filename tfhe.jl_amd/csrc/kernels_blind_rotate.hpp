@@ -1161,19 +1161,21 @@ __device__ __forceinline__ void dft4(cplx (&x)[4])
 
 struct H2LaneTw { cplx tw1[4], tw2[4], tw3[4]; };
 
-// dft4<false> of x[r] = S_r x'[r] with S = (1, s1, c2, s1 c3 / c1), c_r = cos(pi r/16): what blind_rotate_kernel_h2's first stage
-// leaves when the register part of the twist is applied in tan form (load_digits2t); the scales ride on the additions as FMAs
-__device__ __forceinline__ void dft4_fwd_scaled(cplx (&x)[4], double s1)
+// dft4<false> of x[r] = S_r x'[r] with S = (1, s1, g0, s1 g1): what a first stage leaves when the register part of the twist is
+// applied in tan form (load_digits2t / load_digits4t); the scales ride on the additions as FMAs.
+// blind_rotate_kernel_h2: S = (1, c1 [/ sqrt 2], c2, c3 [/ sqrt 2]), c_r = cos(pi r/16); N = 512: S = (1, c2, c4, c2)
+struct Dft4Scale { double g0, g1, s1; };
+__device__ __forceinline__ void dft4_fwd_scaled(cplx (&x)[4], Dft4Scale k)
 {
-    const cplx a = axpy(x[0], kTwG0, x[2]), b = axpy(x[0], -kTwG0, x[2]), c = axpy(x[1], kTwR1, x[3]), d = axpy(x[1], -kTwR1, x[3]);
+    const cplx a = axpy(x[0], k.g0, x[2]), b = axpy(x[0], -k.g0, x[2]), c = axpy(x[1], k.g1, x[3]), d = axpy(x[1], -k.g1, x[3]);
     const cplx id = mk(d.y, -d.x);
-    x[0] = axpy(a, s1, c); x[2] = axpy(a, -s1, c); x[1] = axpy(b, s1, id); x[3] = axpy(b, -s1, id);
+    x[0] = axpy(a, k.s1, c); x[2] = axpy(a, -k.s1, c); x[1] = axpy(b, k.s1, id); x[3] = axpy(b, -k.s1, id);
 }
 
 template <bool SCALED = false>
-__device__ __forceinline__ void fft256_fwd(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb, double s1 = 1.0)
+__device__ __forceinline__ void fft256_fwd(int lane, cplx (&x)[4], const H2LaneTw &w, cplx *tb, Dft4Scale k = Dft4Scale{1.0, 1.0, 1.0})
 {
-    if (SCALED) dft4_fwd_scaled(x, s1); else dft4<false>(x);
+    if (SCALED) dft4_fwd_scaled(x, k); else dft4<false>(x);
 #pragma unroll
     for (int q = 0; q < 4; q++) x[q] = cmul(x[q], w.tw1[q]);
 #pragma unroll
@@ -1358,7 +1360,7 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
             }
         }
         STAMP(1);
-        fft256_fwd<true>(lane, x, tw, tb, h ? kTwSL : kTwL);      // c1 / sqrt(2) : c1
+        fft256_fwd<true>(lane, x, tw, tb, Dft4Scale{kTwG0, kTwR1, h ? kTwSL : kTwL});      // s1 = c1 / sqrt(2) : c1
         STAMP(2);
         cplx own[4], oth[4];                     // this wave's contribution to output component c / 1 - c (half h)
 #pragma unroll

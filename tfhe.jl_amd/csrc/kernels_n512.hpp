@@ -41,33 +41,34 @@ struct N512Args {
     int32_t prio_steps;
 };
 
-// x[r] = (d[t + 64 r] - i d[t + 64 r + 256]) e^{-i pi r/8}: the register part of the twist e^{-i pi (t + 64 r)/512}   polynomials.jl:110
-__device__ __forceinline__ void load_digits4(const int32_t (&temp)[8], int p, int log2_base, cplx (&x)[4])
+// u[r] = (d[t + 64 r] - i d[t + 64 r + 256]) e^{-i pi r/8} / twk(2 r): the register part of the twist e^{-i pi (t + 64 r)/512}
+// (polynomials.jl:110) in tan form (br_core.hpp, twist_tan); the cosines (1, c2, c4, c2) ride on the first butterfly (kN512Scale)
+__device__ __forceinline__ void load_digits4t(const int32_t (&temp)[8], int p, int log2_base, cplx (&u)[4])
 {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const double lo = (double)digit2(temp[r], p, log2_base);
-        const double hi = (double)digit2(temp[r + 4], p, log2_base);
-        if (r == 0) x[r] = mk(lo, -hi);
-        else x[r] = mk(lo * twc(2 * r) - hi * tws(2 * r), -(lo * tws(2 * r) + hi * twc(2 * r)));
-    }
+#define TFHE_TW_(R) u[R] = twist_tan<2 * R>((double)digit2(temp[R], p, log2_base), (double)digit2(temp[R + 4], p, log2_base))
+    TFHE_TW_(0); TFHE_TW_(1); TFHE_TW_(2); TFHE_TW_(3);
+#undef TFHE_TW_
 }
+#define kN512Scale Dft4Scale{kTwR0, 1.0, kTwG0}      // S = (1, c2, c4, c2): g0 = c4, g1 = c2 / c2, s1 = c2
 // conj(y) e^{-i pi r/8}: real -> coefficient t + 64 r, imaginary -> t + 64 r + 256; round, add   polynomials.jl:115-116,127-129
+// (tan form; the cosine rides on the FMA that adds the rounding constant: untwist_add2)
 template <bool MARGIN>
 __device__ __forceinline__ void untwist_add4(const cplx (&y)[4], int32_t (&acc)[8], double &worst)
 {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        double re, im;
-        if (r == 0) { re = y[r].x; im = -y[r].y; }
-        else { re = y[r].x * twc(2 * r) - y[r].y * tws(2 * r); im = -(y[r].x * tws(2 * r) + y[r].y * twc(2 * r)); }
+        double zr, zi;
+        if (r == 0) { zr = y[r].x; zi = y[r].y; }
+        else if (r == 2) { zr = y[r].x - y[r].y; zi = y[r].y + y[r].x; }
+        else if (r == 1) { zr = fma_(-twt(2), y[r].y, y[r].x); zi = fma_(twt(2), y[r].x, y[r].y); }
+        else { zr = fma_(twt(6), y[r].x, -y[r].y); zi = fma_(twt(6), y[r].y, y[r].x); }
         if (MARGIN) {
-            const double a = frac_dist(re), b = frac_dist(im);
+            const double a = frac_dist(zr * twk(2 * r)), b = frac_dist(zi * twk(2 * r));
             worst = a > worst ? a : worst;
             worst = b > worst ? b : worst;
         }
-        acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(re));
-        acc[r + 4] = (int32_t)((uint32_t)acc[r + 4] + (uint32_t)round_to_torus32(im));
+        acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_scaled_to_torus32(zr, twk(2 * r)));
+        acc[r + 4] = (int32_t)((uint32_t)acc[r + 4] + (uint32_t)round_scaled_to_torus32(zi, -twk(2 * r)));
     }
 }
 
@@ -137,8 +138,8 @@ __global__ __launch_bounds__(64 * RW, 3) void blind_rotate_kernel_n512(N512Args 
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) { k0[q4] = kp[q4 * 64]; k1[q4] = kp[kM5 + q4 * 64]; }       // requested before the transform
                 cplx x[4];
-                load_digits4(temp, p + 1, beta, x);
-                fft256_fwd(lane, x, tw, tb);
+                load_digits4t(temp, p + 1, beta, x);
+                fft256_fwd<true>(lane, x, tw, tb, kN512Scale);
                 // out[co] (+)= D[p, c] .* BK_i[p, c].a[co]   (tgsw.jl:128); the step's first transform writes (nothing to zero)
                 if (c == 0 && p == 0) {
 #pragma unroll
@@ -281,8 +282,8 @@ __global__ __launch_bounds__(128, 3) void blind_rotate_kernel_n512w2(N512Args P)
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) { kown[q4] = kp[(size_t)wv * kM5 + q4 * 64]; koth[q4] = kp[(size_t)(1 - wv) * kM5 + q4 * 64]; }
             cplx x[4];
-            load_digits4(temp, p + 1, beta, x);
-            fft256_fwd(lane, x, tw, tb);
+            load_digits4t(temp, p + 1, beta, x);
+            fft256_fwd<true>(lane, x, tw, tb, kN512Scale);
             if (p == 0) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) { own[q4] = cmul(x[q4], kown[q4]); oth[q4] = cmul(x[q4], koth[q4]); }
