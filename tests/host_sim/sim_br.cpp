@@ -171,7 +171,7 @@ double sim_blind_rotate(const int32_t *bara, int32_t n, int32_t L, int32_t log2_
 }
 
 // blind_rotate_kernel_v3's lane code (the shipped path): rotate_sub3 on mirror-extended polynomial images /
-// load_digits2 / tw1f-folded passes / untwist_add2, lane by lane.  bk spectra in engine order as sim_bk_prepare produces them.
+// load_digits2t + dft8_fwd_tw (the constant twist in tan form, as the device kernels) / tw1f-folded passes / untwist_add2, lane by lane.  bk spectra in engine order as sim_bk_prepare produces them.
 double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t log2_base, int32_t mu,
                            const double *bk_spec, int32_t *ext)
 {
@@ -213,7 +213,7 @@ double sim_blind_rotate_v3(const int32_t *bara, int32_t n, int32_t L, int32_t lo
             }
             for (int p = 1; p <= L; p++) {
                 Regs x;
-                for (int l = 0; l < 64; l++) { load_digits2(temp[l], p, log2_base, x[l]); fwd2_pass_a(x[l], tw[l]); x1_store_a(l, x[l], xch.data()); }
+                for (int l = 0; l < 64; l++) { load_digits2t(temp[l], p, log2_base, x[l]); dft8_fwd_tw(x[l]); for (int q = 0; q < 8; q++) x[l][q] = cmul(x[l][q], tw[l].tw1f[q]); x1_store_a(l, x[l], xch.data()); }
                 for (int l = 0; l < 64; l++) x1_load_b(l, x[l], xch.data());
                 for (int l = 0; l < 64; l++) { fwd2_pass_b(x[l], tw[l]); x2_store(l, x[l], xch.data()); }
                 for (int l = 0; l < 64; l++) x2_load(l, x[l], xch.data());
