@@ -33,6 +33,6 @@ for B in [int(v) for v in a.sizes.split(",")]:
             res.setdefault(name + "/kernel", kern)
             if ref is None: ref = out
             assert np.array_equal(out, ref), (B, name)
-            for k, v in opts: eng.set_option(k, {"br_split": 1, "k2_rw": 0, "k2_w3": -1, "v3_rw": 0, "w2_rw": 0, "br_small": 1024}.get(k, 0))
+            for k, v in opts: eng.set_option(k, {"br_split": 1, "k2_rw": 0, "k2_w3": -1, "v3_rw": 0, "w2_rw": 0, "br_small": 1024, "br_prio_pct": 90}.get(k, 0))
     print(json.dumps({"params": a.params, "rotations": B, **{n: (round(float(np.median(v)), 3) if isinstance(v, list) else v) for n, v in res.items()}}), flush=True)
 ck.close()
