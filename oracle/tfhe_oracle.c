@@ -152,7 +152,7 @@ static int g_nplans = 0;
 int orc_init(int32_t N)
 {
     for (int i = 0; i < g_nplans; i++) if (g_plans[i].N == N) return 0;
-    if (g_nplans >= 16 || N > ORC_MAX_N || N < 4 || (N & (N - 1))) return -1;
+    if (g_nplans >= 16 || N > ORC_MAX_N || N < 2 || (N & (N - 1))) return -1;
     orc_plan *p = &g_plans[g_nplans];
     const int M = N / 2;
     p->N = N; p->M = M;
