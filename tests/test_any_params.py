@@ -473,3 +473,15 @@ def test_n512_full_size_set(tfhe, orc):
         assert np.array_equal(got_huge[r * B:(r + 1) * B], first), r
     assert np.array_equal(got_huge[3 * B:], first[:4400 - 3 * B])
     K.ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,cases,seed", [("fuzz_params.py", 80, 21), ("fuzz_mk_params.py", 30, 22)])
+def test_parameter_space_fuzz(script, cases, seed):
+    """A short run of the parameter-space fuzzers (tests/fuzz_params.py, tests/fuzz_mk_params.py: random sets over everything
+    tfhe_ctx_create accepts, every one against the oracle word for word; the long runs are in profiles/r13_fuzz_*.txt)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, script), str(cases), str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz ok" in r.stdout, r.stdout[-500:]
