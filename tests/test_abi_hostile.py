@@ -111,3 +111,67 @@ def test_hostile_arguments_return_errors(tfhe, orc, keys80):
     got = eng.gates(ops, x, y)
     assert np.array_equal(got, K.oracle.gates(ops, x, y, nthreads=4))
     assert list(tfhe.decrypt(K.sk, got)) == [False, True, True]
+
+
+@pytest.mark.gpu
+def test_hostile_arguments_multi_key_and_multi_device(tfhe, orc, keys80):
+    """The same on a multi-key context (single-key entry points refused, NULL / negative arguments) and on a {0, 0} multi-device
+    context (wire-table calls with indices outside the table, device-pointer calls)."""
+    from tfhe_jl_amd import _lib as L
+    lib = L.load()
+    vp, NULL = C.c_void_p, None
+    p = lambda a: a.ctypes.data_as(vp)
+    bad = []
+
+    def expect_error(what, rc):
+        if rc == 0: bad.append(what)
+
+    # multi-key, 2 parties, a small set
+    P = tfhe.SchemeParameters(4, 0.012467, 1024, 1, 4, 7, 3.29e-10, 8, 2, 2.44e-5, 2)
+    rng = np.random.default_rng(77)
+    sks = [tfhe.SecretKey(rng, P) for _ in range(2)]
+    shared = tfhe.SharedKey(rng, P)
+    ck = tfhe.MKCloudKey([tfhe.CloudKeyPart(rng, sk, shared) for sk in sks])
+    eng = ck.engine(0)
+    h = eng._h
+    w = 2 * 4 + 1
+    x = tfhe.mk_encrypt(rng, sks, [True, False])
+    y = tfhe.mk_encrypt(rng, sks, [True, True])
+    out = np.zeros((2, w), np.int32)
+    ops = np.zeros(2, np.uint8)
+    expect_error("mk_gate_nand NULL in0", lib.tfhe_mk_gate_nand_batch(h, NULL, p(y), p(out), 2))
+    expect_error("mk_gate_nand NULL out", lib.tfhe_mk_gate_nand_batch(h, p(x), p(y), NULL, 2))
+    expect_error("mk_gate_nand B < 0", lib.tfhe_mk_gate_nand_batch(h, p(x), p(y), p(out), -2))
+    expect_error("gates_batch on a multi-key ctx", lib.tfhe_gates_batch(h, p(ops), p(x), p(y), NULL, p(out), 2))
+    expect_error("bootstrap_batch on a multi-key ctx", lib.tfhe_bootstrap_batch(h, 1 << 29, p(x), p(out), 2, 1))
+    expect_error("load_keyswitch_key on a multi-key ctx", lib.tfhe_load_keyswitch_key(h, p(x)))
+    expect_error("mk_load_bootstrap_key NULL", lib.tfhe_mk_load_bootstrap_key_i32(h, NULL, 2))
+    expect_error("mk_load_bootstrap_key 0 parties", lib.tfhe_mk_load_bootstrap_key_i32(h, p(ck.bootstrap_key), 0))
+    expect_error("mk_load_bootstrap_key 3 parties on max_parties = 2", lib.tfhe_mk_load_bootstrap_key_i32(h, p(ck.bootstrap_key), 3))
+    expect_error("mk_load_keyswitch_key NULL", lib.tfhe_mk_load_keyswitch_key(h, NULL, 2))
+    expect_error("mk_expand NULL parts", lib.tfhe_mk_expand_load_bootstrap_key(h, 2, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL))
+    o = orc.Oracle(4, 1024, 1, 4, 7, 8, 2, parties=2)
+    o.load_bootstrap_key(ck.bootstrap_key)
+    o.load_keyswitch_key(ck.keyswitch_key)
+    assert np.array_equal(eng.mk_gate_nand(x, y), o.mk_gate_nand(x, y, nthreads=4))       # still sound
+    # {0, 0} multi-device context
+    K = keys80
+    m = K.ck.engine([0, 0])
+    hm = m._h
+    n1 = K.params.lwe_size + 1
+    a = tfhe.encrypt(K.rng, K.sk, [True, False, True]).data
+    idx = np.array([0, 1, 2], np.int32)
+    ops3 = np.zeros(3, np.uint8)
+    o3 = np.zeros((3, n1), np.int32)
+    expect_error("multi: gates_level without a table", lib.tfhe_gates_level(hm, p(ops3), p(idx), p(idx), NULL, p(idx), 3))
+    assert lib.tfhe_wires_alloc(hm, 8) == 0
+    expect_error("multi: wires_upload past the end", lib.tfhe_wires_upload(hm, 7, 3, p(a)))
+    expect_error("multi: wires_gather index 99", lib.tfhe_wires_gather(hm, p(np.array([0, 99], np.int32)), 2, p(o3)))
+    expect_error("multi: gates_level operand outside", lib.tfhe_gates_level(hm, p(ops3), p(np.array([0, 1, 8], np.int32)), p(idx), NULL, p(np.array([3, 4, 5], np.int32)), 3))
+    expect_error("multi: gates_level NULL opcodes", lib.tfhe_gates_level(hm, NULL, p(idx), p(idx), NULL, p(np.array([3, 4, 5], np.int32)), 3))
+    expect_error("multi: gates_batch_dev (device pointers belong to one device)", lib.tfhe_gates_batch_dev(hm, p(ops3), p(a), p(a), NULL, p(o3), 3, NULL))
+    expect_error("multi: gates_batch NULL out", lib.tfhe_gates_batch(hm, p(ops3), p(a), p(a), NULL, NULL, 3))
+    expect_error("multi: level_exchange = 7", lib.tfhe_set_option(hm, b"level_exchange", 7))
+    assert not bad, f"accepted without an error: {bad}"
+    b = tfhe.encrypt(K.rng, K.sk, [True, True, False]).data
+    assert np.array_equal(m.gates(ops3, a, b), K.oracle.gates(ops3, a, b, nthreads=4))
