@@ -4,8 +4,10 @@
  * The reference (nucypher/TFHE.jl) has no FFI for this path: it is plain Julia.  This header is the
  * drop-in boundary a `ccall` shim binds instead of the Julia functions cited per entry point
  * (paths relative to the reference checkout).  Plain pointers and sizes only; no C++ types, no
- * exceptions cross the boundary.  Every function returns 0 on success or a TFHE_ERR_* code;
- * tfhe_last_error() gives the message for the last failure on that context.
+ * exceptions cross the boundary: every entry point catches what its C++ body throws (a std::vector or std::thread that could
+ * not be had: TFHE_ERR_NOMEM; anything else: TFHE_ERR_STATE with the exception's text) and the context stays usable — under a
+ * Julia `ccall` or Python `ctypes` an escaping exception would end the process.  Every function returns 0 on success or a
+ * TFHE_ERR_* code; tfhe_last_error() gives the message for the last failure on that context.
  *
  * Data formats (all Torus32 = int32_t, wrapping two's-complement arithmetic):
  *   LWE sample      : int32[n+1]          = a[0..n-1], b            (lwe.jl:21-29)
@@ -32,6 +34,8 @@
  * inside an entry point owns the context until that call returns, and a call made meanwhile from another thread fails with
  * TFHE_ERR_STATE (tfhe_last_error then tells that thread why) instead of racing on the context's workspaces.  Give every
  * host thread its own context (keys are per context), or serialise the calls (the Julia binding holds a ReentrantLock).
+ * Two entry points are exempt and may be called from any thread at any time: tfhe_ctx_synchronize and tfhe_gates_batch_wait
+ * (which then waits as tfhe_ctx_synchronize does) — what a finalizer needs before it frees the buffers of a submitted batch.
  * The asynchronous forms (tfhe_gates_batch_submit, tfhe_gates_batch_dev, tfhe_gates_level) return while the device works;
  * only their host side is a "call" in this sense.
  *
@@ -77,7 +81,7 @@
 extern "C" {
 #endif
 
-#define TFHE_MI355X_ABI_VERSION 6
+#define TFHE_MI355X_ABI_VERSION 7
 
 /* Scheme parameters — the fields of SchemeParameters the hot path reads (api.jl:4-21). */
 typedef struct tfhe_params {
@@ -100,7 +104,9 @@ enum {
     TFHE_ERR_UNSUPPORTED = 2,  /* parameter set outside what the kernels are built for      */
     TFHE_ERR_NO_KEY = 3,       /* a key needed by the call has not been loaded              */
     TFHE_ERR_DEVICE = 4,       /* HIP runtime error (no device, allocation, launch, ...)    */
-    TFHE_ERR_STATE = 5
+    TFHE_ERR_STATE = 5,        /* call not possible in the context's state: wrong kind of context, overlapping call
+                                  from another thread, option after the key it decides about; unexpected C++ exception */
+    TFHE_ERR_NOMEM = 6         /* host memory exhausted inside the library (std::bad_alloc); ABI v7                    */
 };
 
 /* Gate opcodes for tfhe_gates_batch — one per exported gate_* function (TFHE.jl:34-46). */
@@ -125,7 +131,9 @@ enum {
 
 /* ---- library / context ------------------------------------------------------------------- */
 
-/* ABI version of the loaded library (== TFHE_MI355X_ABI_VERSION it was built with). */
+/* ABI version of the loaded library (== TFHE_MI355X_ABI_VERSION it was built with).  NEGATIVE: a development build
+ * (-DTFHE_EXPERIMENT, csrc/experiment.hpp: in-kernel stamps, environment-variable overrides) that a binding must refuse
+ * unless its user asked for it. */
 int32_t tfhe_abi_version(void);
 
 /* Number of HIP devices visible to this process (<0: runtime error). */
@@ -168,6 +176,13 @@ const char *tfhe_last_error(const tfhe_ctx *ctx);
 
 /* Copies the parameters the context was created with. */
 int32_t tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
+
+/* Blocks until everything queued on ctx so far has completed: its own stream, its second stream (tfhe_gates_batch_submit),
+ * every device of a multi-device context.  Takes no ownership of the context and touches none of its state: callable from ANY
+ * thread, also while another thread is inside a call on ctx (ABI v7).  For code that must release the host buffers of a submitted
+ * batch without being the context's caller — a garbage collector's finalizer, an error path: after it returns TFHE_OK no DMA
+ * of an earlier submit is still reading or writing them. */
+int32_t tfhe_ctx_synchronize(tfhe_ctx *ctx);
 
 /* ---- keys (replace CloudKey's object graphs, api.jl:111-127) -------------------------------- */
 
@@ -232,6 +247,8 @@ int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *i
  * (every other one). */
 int32_t tfhe_gates_batch_submit(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                                 const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket);
+/* wait: callable from any thread (ABI v7).  From a thread other than the one inside a call on ctx it waits for everything queued
+ * on ctx (tfhe_ctx_synchronize) instead of failing with TFHE_ERR_STATE. */
 int32_t tfhe_gates_batch_wait(tfhe_ctx *ctx, int32_t ticket);
 
 /* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`
@@ -339,13 +356,28 @@ int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 
 /* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
  * "measure_margin", "mk_general", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
- * csrc/tfhe_engine.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
+ * csrc/engine_diag.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
  * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise).
  * "br_rt_l" = 1 runs l = 2 / 3 on the run-time-l instantiations as well (they are otherwise used for every other l; a
  * comparison switch).  "timing_events" (default 1): 0 makes the gate entry points record no per-phase timing events — each record keeps the stream's
  * next kernel waiting ~5 us, which a level of a narrow circuit (six short operations around one single-rotation kernel) feels;
  * tfhe_last_timing_ms / tfhe_timing_history_ms then have nothing to report for those calls (TFHE_ERR_STATE). */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
+/* Read-only names of tfhe_get_option (ABI v7), decided by tfhe_ctx_create from the parameter set alone — is it inside what a
+ * Float64 transform computes exactly ("Exactness domain" above)?
+ *   "exact_domain"            2 = every result word is the exact product for ANY Int32 key words: the worst-case pre-rounding
+ *                                 magnitude np N 2^(beta-1) 2^31 (np = (k+1) l products per output; multi-key (P+1) l) is below 2^51
+ *                                 and the predicted rounding margin below 1/4  (tfhe_parameters_128, the multi-key sets);
+ *                             1 = the same for every REAL key (uniform mask words: 8 x rms magnitude below 2^51), but not for an
+ *                                 adversarial one  (tfhe_parameters_80: its all-keys bound is exactly 2^52);
+ *                             0 = outside: the predicted margin reaches 1/4 (or the magnitude 2^51).  The engine still computes —
+ *                                 the reference does too and warns (polynomials.jl:135-144) — but a word may differ from the exact
+ *                                 product; tfhe_last_rounding_margin measures.  The Python and Julia constructors warn once.
+ *   "exact_bound_log2_x1000"  1000 x log2 of that worst-case magnitude
+ *   "exact_margin_x1e6"       10^6 x the predicted margin = 4 x 2^-53 x rms x log2(N/2), rms = sqrt(np N) 2^(beta+32) / 12; every
+ *                             measured margin of rounds 2-5 lies between 0.35 and 0.9 of it
+ * "debug_fail_alloc_after" (set / get, ctx may be NULL, process-wide, default 0 = off): the n-th allocation checkpoint inside the
+ * library from now on throws std::bad_alloc — how the tests show that TFHE_ERR_NOMEM comes back and the context survives. */
 /* The current value of an option (ABI v6): a caller that changes one for a while can put it back.  "br_anyn" (the any-N kernel
  * where a tuned one exists; like "ks_variant" it decides a key layout and must be chosen before the bootstrapping key is
  * loaded), "anyn_spec", "level_exchange", "k2_w3", "n512_rw", "n512_w2" (which N = 512 / k = 2 kernel a batch size takes) are new in v6. */

@@ -48,9 +48,14 @@ for case in range(cases):
     again = eng.mk_gate_nand(x, y)
     margin = eng.last_rounding_margin()
     eng.set_option("measure_margin", 0)
-    if margin >= 0.25:
+    # inside the Float64 exactness domain?  decided from the parameters alone (SchemeParameters.exactness), as tests/fuzz_params.py does
+    cls, bound_log2, predicted = p.exactness()
+    assert eng.get_option("exact_domain") == cls, (p, cls)
+    if cls >= 1:
+        assert margin < 0.25 and margin <= max(predicted, 0.02), f"case {case}: margin {margin} above the prediction {predicted} inside the exactness domain: {p} parties {parties} kernel {kern}"
+    elif margin >= 0.25:
         outside += 1
-        print(f"case {case:4d} P={parties} N={N:5d} l={l:2d} beta={beta} n={n} margin {margin:.4f}: outside the Float64 domain, skipped  {kern}", flush=True)
+        print(f"case {case:4d} P={parties} N={N:5d} l={l:2d} beta={beta} n={n} margin {margin:.4f} (predicted {predicted:.2f}, class 0): outside the Float64 domain, skipped  {kern}", flush=True)
         continue
     assert np.array_equal(got, want), f"case {case}: words differ (margin {margin}): {p} parties {parties} kernel {kern}"
     assert np.array_equal(again, want), f"case {case}: DIAG words differ: {p} parties {parties} kernel {kern}"

@@ -45,11 +45,19 @@ for case in range(cases):
     again = eng.bootstrap(MU, x, with_keyswitch=False)
     margin = eng.last_rounding_margin()
     eng.set_option("measure_margin", 0)
-    if margin >= 0.25:
+    # Is the set inside the Float64 exactness domain?  Decided WITHOUT the engine under test: SchemeParameters.exactness() is the
+    # a-priori law of (N, k, l, beta), which the engine must restate (tfhe_get_option "exact_domain").  Inside it
+    # (class 1 or 2) nothing is skipped: the measured margin must stay below 1/4 and below the prediction, and every word is
+    # compared.  Outside (class 0) the words are compared only where the measured margin still allows.
+    cls, bound_log2, predicted = p.exactness()
+    assert eng.get_option("exact_domain") == cls and abs(eng.get_option("exact_margin_x1e6") / 1e6 - predicted) < 1e-5 + 1e-6 * predicted, (p, cls, predicted)
+    if cls >= 1:
+        assert margin < 0.25 and margin <= max(predicted, 0.02), f"case {case}: margin {margin} above the prediction {predicted} inside the exactness domain: {p} kernel {kern}"
+    elif margin >= 0.25:
         # a pre-rounding value this far from an integer: the set is outside what a Float64 transform computes exactly (the
         # reference's own FFTW transform rounds such values its own way, polynomials.jl:115-116) — nothing to compare
         outside += 1
-        print(f"case {case:4d} N={N:5d} k={k} l={l:2d} beta={beta:2d} n={n:2d} margin {margin:.4f}: outside the Float64 domain, skipped  {kern}", flush=True)
+        print(f"case {case:4d} N={N:5d} k={k} l={l:2d} beta={beta:2d} n={n:2d} margin {margin:.4f} (predicted {predicted:.2f}, class 0): outside the Float64 domain, skipped  {kern}", flush=True)
         K.ck.close()
         continue
     assert np.array_equal(got, want), f"case {case}: rotation words differ (margin {margin}): {p} kernel {kern}"
@@ -61,6 +69,10 @@ for case in range(cases):
     gw = K.oracle.gates(ops, *ins, nthreads=8)
     gg = eng.gates(ops, *ins)
     assert np.array_equal(gg, gw), f"case {case}: gate words differ: {p} kernel {kern} / {eng.last_kernel_name()}"
-    print(f"case {case:4d} N={N:5d} k={k} l={l:2d} beta={beta:2d} n={n:2d} t={t:2d} gamma={gamma} B={B:2d} margin {margin:.4f}  {kern}", flush=True)
+    # the oracle's own Float64 transform (radix-2, one rounding per output as the reference) measures a margin of the same size
+    om = K.oracle.last_margin
+    assert cls == 0 or om < 0.25, (case, om)
+    assert margin <= 4 * max(om, 0.01) and om <= 4 * max(margin, 0.01), f"case {case}: engine margin {margin} vs oracle margin {om}: {p} kernel {kern}"
+    print(f"case {case:4d} N={N:5d} k={k} l={l:2d} beta={beta:2d} n={n:2d} t={t:2d} gamma={gamma} B={B:2d} margin {margin:.4f} (oracle {om:.4f}, predicted {predicted:.4f}, class {cls})  {kern}", flush=True)
     K.ck.close()
 print(f"fuzz ok: {cases} parameter sets ({outside} outside the Float64 domain, skipped) in {time.time() - t0:.1f} s; largest rounding margin {worst[0]:.4f} at (N, k, l, beta, n) = {worst[1]}")

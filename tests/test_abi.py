@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(tfhe):
     for s in syms:
         assert hasattr(lib, s), f"libtfhe_mi355x.so does not export {s}"
     assert sorted(tfhe._lib.ABI_SYMBOLS) == syms
-    assert lib.tfhe_abi_version() == 6
+    assert lib.tfhe_abi_version() == 7      # (a development build would answer -7 and tfhe._lib.load() would have refused it)
 
 
 def test_opcode_numbering_matches_header(tfhe, orc):

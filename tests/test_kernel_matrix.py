@@ -1,5 +1,5 @@
 """Every blind-rotate kernel instantiation the dispatcher can select (launch_blind_rotate / tfhe_mk_gate_nand_batch in
-csrc/tfhe_engine.hip), driven through the C ABI at an option setting or batch size that selects it, against the oracle
+csrc/engine_dispatch.hip, engine_multikey.hip), driven through the C ABI at an option setting or batch size that selects it, against the oracle
 word for word; its DIAG instantiation must give the same words with a rounding margin far from a flipped rounding
 (the reference rounds at polynomials.jl:115-116; its multi-key code sums products in Int32 precisely because it does
 not trust spectrum-domain sums, mk_internals.jl:359-366 — here the margin of doing so is measured on the GPU).

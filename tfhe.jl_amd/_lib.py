@@ -22,9 +22,10 @@ ABI_SYMBOLS = [
     "tfhe_last_kernel_name", "tfhe_last_kernel_clock_mhz", "tfhe_mk_load_bootstrap_key_c128",
     "tfhe_mk_expand_load_bootstrap_key", "tfhe_keygen_cloud_key", "tfhe_host_alloc", "tfhe_host_free",
     "tfhe_timing_history_ms", "tfhe_gates_batch_submit", "tfhe_gates_batch_wait", "tfhe_last_device_count",
-    "tfhe_get_option",
+    "tfhe_get_option", "tfhe_ctx_synchronize",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
+ERR_NOMEM = 6
 
 OPCODES = dict(NAND=0, OR=1, AND=2, XOR=3, XNOR=4, NOT=5, NOR=6, ANDNY=7, ANDYN=8, ORNY=9, ORYN=10,
                MUX=11, CONST0=12, CONST1=13, COPY=14)
@@ -60,6 +61,19 @@ class EngineError(RuntimeError):
 
 
 _lib = None
+_warned_inexact = set()
+
+
+def _warn_inexact_once(params, margin, bound_log2):
+    key = params.engine_tuple()
+    if key in _warned_inexact:
+        return
+    _warned_inexact.add(key)
+    import warnings
+    warnings.warn(f"TFHE parameter set {key} (lwe_size, N, k, l, log2 Bg, t, log2 ks_base, parties) is outside the Float64 exactness "
+                  f"domain: predicted rounding margin {margin:.2f} (a flipped rounding needs 0.5), worst-case magnitude 2^{bound_log2:.1f}. "
+                  "The engine computes as the reference does, but result words may differ from the exact negacyclic product; "
+                  "tfhe_last_rounding_margin measures the actual margin.", RuntimeWarning, stacklevel=3)
 
 
 def load():
@@ -123,8 +137,14 @@ def load():
     lib.tfhe_last_kernel_name.argtypes = [vp]
     lib.tfhe_last_kernel_name.restype = C.c_char_p
     lib.tfhe_last_kernel_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
-    if lib.tfhe_abi_version() != ABI_VERSION and not os.environ.get("TFHE_MI355X_ALLOW_ABI_MISMATCH"):     # (the override is for A/B runs against an older build)
-        raise ImportError(f"{LIB_PATH} has ABI version {lib.tfhe_abi_version()}, this package needs {ABI_VERSION}: rebuild it")
+    if hasattr(lib, "tfhe_ctx_synchronize"):
+        lib.tfhe_ctx_synchronize.argtypes = [vp]
+    ver = lib.tfhe_abi_version()
+    if ver < 0 and not os.environ.get("TFHE_MI355X_ALLOW_EXPERIMENT"):
+        # a development build (-DTFHE_EXPERIMENT: in-kernel stamps, environment-variable overrides; csrc/experiment.hpp)
+        raise ImportError(f"{LIB_PATH} is a development build (ABI version {ver}): set TFHE_MI355X_ALLOW_EXPERIMENT=1 to load it knowingly")
+    if abs(ver) != ABI_VERSION and not os.environ.get("TFHE_MI355X_ALLOW_ABI_MISMATCH"):     # (the override is for A/B runs against an older build)
+        raise ImportError(f"{LIB_PATH} has ABI version {ver}, this package needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 
@@ -171,6 +191,11 @@ class Engine:
         self._h = h
         self._in_flight = {}
         self.device = self.devices[0]
+        # is this parameter set inside what a Float64 transform computes exactly?  (decided by tfhe_ctx_create from the parameters
+        # alone; the reference warns about the same thing, polynomials.jl:135-144)
+        self.exact_domain = self.get_option("exact_domain")
+        if self.exact_domain == 0:
+            _warn_inexact_once(params, self.get_option("exact_margin_x1e6") / 1e6, self.get_option("exact_bound_log2_x1000") / 1e3)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -272,6 +297,13 @@ class Engine:
     def gates_wait(self, ticket):
         self._check(self._lib.tfhe_gates_batch_wait(self._h, int(ticket)))
         self._in_flight.pop(int(ticket), None)
+
+    def synchronize(self):
+        """Blocks until everything queued on the context has completed (tfhe_ctx_synchronize): callable from any thread, also
+        while another thread is inside a call on this engine."""
+        rc = self._lib.tfhe_ctx_synchronize(self._h)
+        if rc != 0:
+            raise EngineError(rc, "tfhe_ctx_synchronize failed")
 
     def gates_dev(self, opcodes, d_in0, d_in1, d_in2, d_out, B, stream=0):
         """Device-pointer variant: operands are integer device addresses (e.g. torch tensor .data_ptr())."""

@@ -368,7 +368,7 @@ TFHE_HD void rotate_sub2(int lane, int a_mod_2N, const int32_t *acc_lds, const i
     for (int m = 0; m < 16; m++) {
         const int idx = base + 64 * m;                         // bit 10 (mod 2N) = sign, low 10 bits = position
         const int32_t v = acc_lds[idx & (kN - 1)];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TFHE_NO_BFE)
+#if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t sgn = (uint32_t)__builtin_amdgcn_sbfe(idx, 10u, 1u);     // 0 or 0xFFFFFFFF
 #else
         const uint32_t sgn = (idx & kN) ? 0xFFFFFFFFu : 0u;
@@ -432,7 +432,7 @@ TFHE_HD void store_cur(int lane, const int32_t (&acc)[NBLK], int32_t *img)
 // digit p (1-based) of a prepared coefficient: signed bit-field extract of bits [32 - p beta, 32 - (p-1) beta)
 TFHE_HD int32_t digit2(int32_t t, int p, int log2_base)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(TFHE_NO_BFE)
+#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sbfe(t, (unsigned)(32 - p * log2_base), (unsigned)log2_base);   // one v_bfe_i32
 #else
     return (int32_t)((uint32_t)t << ((p - 1) * log2_base)) >> (32 - log2_base);

@@ -173,9 +173,10 @@ __host__ __device__ inline size_t lds_bytes(int N, int nspec_in_lds)
 }
 __host__ inline int threads_for(int N)
 {
-    // (measurement aid: TFHE_ANYN_THREADS overrides)
+#ifdef TFHE_EXPERIMENT      // (measurement aid of development builds: TFHE_ANYN_THREADS overrides)
     static const char *env = getenv("TFHE_ANYN_THREADS");
     if (env && atoi(env) >= 64) return atoi(env) > 512 ? 512 : atoi(env) / 64 * 64;
+#endif
     // Measured (profiles/r05/r05j_anyn_threads.txt; blind rotate of 4096 / 2048 / 1024 / 512 gates at N = 512 / 1024 / 2048 / 4096):
     //   N = 512:  64 threads 35.3 ms, 128: 30.7, 256: 38.3      N = 1024: 64: 45.9, 128: 32.1, 256: 26.7, 512: 38.3
     //   N = 2048: 128: 92.4, 256: 65.7, 512: 54.9                 N = 4096: 64: 323, 128: 176, 256: 111-113, 512: 81.4
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(512) void mk_blind_rotate_kernel(Args P)
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
+#ifdef TFHE_EMIT_KEYPREP_KERNELS       // (defined by engine_keys.hip, the one translation unit that launches them)
 // ---- bootstrapping-key preparation --------------------------------------------------------------------------------
 // Int32 polynomial -> spectrum in fft_fwd's order, scaled (1/M for key polynomials: forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(512) void bk_prepare_kernel(const int32_t *__restrict__ polys, cplx *__restrict__ out, const cplx *__restrict__ wtab,
@@ -397,6 +399,7 @@ __global__ void bk_permute_c128_kernel(const cplx *__restrict__ in, cplx *__rest
 // ---- RGSW.Expand (mk_internals.jl:304-345) for any N: the counterpart of mk_expand_kernel (kernels_blind_rotate.hpp) ----------
 //     x[jj, q] = d0[jj] + sum_u g^-1(b_q[jj] - b_i[jj])[u] (*) f0[u]          y[jj, q] = sum_u g^-1(...)[u] (*) f1[u]
 // One workgroup per output polynomial: l spectrum products, one inverse transform, one rounding.
+#endif  // TFHE_EMIT_KEYPREP_KERNELS
 struct MkExpandArgs {
     const cplx *dec;      // [P-1 (other party, in order)][l (u)][l (jj)][M]   digit spectra, unscaled
     const cplx *f;        // [2 (f0 | f1)][n][l (u)][M]                          spectra scaled 1/M
@@ -405,6 +408,7 @@ struct MkExpandArgs {
     const cplx *wtab, *twist;
     int32_t n, l, parties, party, log2N;
 };
+#ifdef TFHE_EMIT_KEYPREP_KERNELS
 __global__ __launch_bounds__(512) void mk_expand_kernel(MkExpandArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,5 +437,6 @@ __global__ __launch_bounds__(512) void mk_expand_kernel(MkExpandArgs A)
         o[t + M] = (int32_t)((xy == 0 ? (uint32_t)d0[t + M] : 0u) + (uint32_t)round_to_torus32(im));
     }
 }
+#endif  // TFHE_EMIT_KEYPREP_KERNELS
 
 }  // namespace anyn

@@ -65,21 +65,13 @@ __device__ __forceinline__ void diag_end(const DiagArgs &d, size_t w, double wor
 // buffers, which half of a split it takes) then lives in scalar registers and branches on it are scalar branches — the
 // compiler cannot see that threadIdx.x >> 6 is wave-uniform and otherwise keeps pointers per lane, masks EXEC around
 // wave-uniform ifs and, in the register-bound kernels, spills those per-lane copies.
-#ifdef TFHE_NO_WAVE_SCALAR       // A/B builds only
-__device__ __forceinline__ int wave_in_block() { return (int)(threadIdx.x >> 6); }
-#else
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-#endif
 // A blind rotation's exponents are read one step ahead through the SCALAR cache (s_load_dword: constant address space): the
 // row was written by the prologue kernel of the same batch call, i.e. before this launch, and the value — the same for
 // every lane — then waits in a scalar register instead of a vector register that is live across the whole step.
 __device__ __forceinline__ int32_t load_uniform_i32(const int32_t *p)
 {
-#ifdef TFHE_NO_UNIFORM_LOAD      // A/B builds only
-    return *p;
-#else
     return *(const __attribute__((address_space(4))) int32_t *)(p);
-#endif
 }
 
 // This thread's lane, recomputed (two instructions) instead of read from the register threadIdx.x arrived in: a kernel that is
@@ -156,11 +148,7 @@ __device__ __forceinline__ void rotate_poly(int lane, int a, const int32_t *img,
     load_cur<NBLK>(lane, img, cur);
     int a_here = __builtin_amdgcn_readfirstlane(a);
     asm volatile("" : "+s"(a_here));
-#ifdef TFHE_ABL_ROT      // timing experiment only (wrong results): no rotated reads
-    for (int m = 0; m < NBLK; m++) temp[m] = cur[m] ^ a_here;
-#else
     rotate_sub3<NBLK>(lane, a_here, img, cur, offset, xormask, temp);
-#endif
 }
 // acc += round(untwisted y), image updated in place (mirror included)
 template <bool MARGIN, bool FUSED = true>
@@ -231,11 +219,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
     // second half inside the transform (between the store and the load of its second transposition, where x[] is dead),
     // the rest after it.  Interleaved A/B on one device, 4096 rotations: l = 2: 12.86 ms against 13.07 with the whole chunk
     // a transform ahead (KPF == 16) and 12.98 with KMID = 0; l = 3: 21.53 against 21.47.  Only <l, 8, tw2reg> is instantiated since round 4.
-#ifdef TFHE_V3_KMID      // A/B builds only
-    constexpr int KMID = (KPF == 8) ? TFHE_V3_KMID : 0;
-#else
     constexpr int KMID = (KPF == 8) ? 4 : 0;
-#endif
     // L = 0: the decomposition length is a run-time value (P.l) — the transform loop is rolled and nothing else depends on it —
     // so ONE instantiation serves every l no shipped parameter set uses at the speed of the tuned ones
     const int Lr = L ? L : P.l;
@@ -297,54 +281,34 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
             const int c = L ? f / (L ? L : 1) : (f >= Lr), p = L ? f % (L ? L : 1) : f - c * Lr;        // component, digit index (0-based)
             if (p == 0) rotate_poly<16>(lane, a, acc_lds + c * kImg, P.g.offset, xormask, temp);
             cplx x[8];
-#ifdef TFHE_NO_TANFORM       // A/B builds only: the twist as multiply + FMA per component
-            load_digits2(temp, p + 1, beta, x);
-            dft8<false>(x);
-#else
             load_digits2t(temp, p + 1, beta, x);
             dft8_fwd_tw(x);
-#endif
             // pass A
 #pragma unroll
             for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
-#ifndef TFHE_ABL_X1
             x1_store_a(lane, x, xch);
             WAVE_LDS_FENCE();
             x1_load_b(lane, x, xch);
-#endif
             // pass B (twiddles from the LDS table)
             {
                 cplx t2[8];
 #pragma unroll
-#ifdef TFHE_ABL_TW2
-                for (int q = 1; q < 8; q++) t2[q] = tw1f[q];
-#else
                 for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
-#endif
                 dft8<false>(x);
 #pragma unroll
                 for (int q = 1; q < 8; q++) x[q] = cmul(x[q], t2[q]);
             }
             WAVE_LDS_FENCE();
-#ifndef TFHE_ABL_X2
             x2_store(lane, x, xch);
-#endif
             WAVE_LDS_FENCE();
             cplx k1v[8];
-#ifdef TFHE_ABL_KEY
-#pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) { k1v[k2] = kbuf[k2]; asm volatile("" : "+v"(k1v[k2].x), "+v"(k1v[k2].y)); }
-#else
             if (KPF == 8 && KMID > 0) {
                 const cplx *kp = key_ptr(i, f);
 #pragma unroll
                 for (int k2 = 0; k2 < KMID; k2++) k1v[k2] = kp[(8 + k2) * 64];
                 WAVE_LDS_FENCE();
             }
-#endif
-#ifndef TFHE_ABL_X2
             x2_load(lane, x, xch);
-#endif
             WAVE_LDS_FENCE();
             dft8<false>(x);
             // MAC: out[co] (+)= D[p, c] .* BK_i[p, c].a[co]        (tgsw.jl:128); f is wave-uniform: a scalar branch
@@ -361,11 +325,9 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
                         for (int k2 = 0; k2 < 8; k2++) out[co][k2] = cfma(x[k2], kbuf[co * 8 + k2], out[co][k2]);
                 }
             } else {
-#ifndef TFHE_ABL_KEY
                 const cplx *kp = key_ptr(i, f);
 #pragma unroll
                 for (int k2 = KMID; k2 < 8; k2++) k1v[k2] = kp[(8 + k2) * 64];
-#endif
                 if (f == 0) {
 #pragma unroll
                     for (int k2 = 0; k2 < 8; k2++) out[0][k2] = cmul(x[k2], kbuf[k2]);
@@ -383,43 +345,29 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_v3(BrArgs P)
                 const bool last = (f + 1 == F);
                 // (unconditional: on the very last transform this re-reads a valid chunk; a conditional
                 //  prefetch doubles the register pressure through the phi of old and new values)
-#ifndef TFHE_ABL_KEY
                 const cplx *kp = last ? key_ptr(i + 1 < P.n ? i + 1 : i, 0) : key_ptr(i, f + 1);
 #pragma unroll
                 for (int j = 0; j < KPF; j++) kbuf[j] = kp[j * 64];
-#else
-                (void)last;
-#pragma unroll
-                for (int j = 0; j < KPF; j++) asm volatile("" : "+v"(kbuf[j].x), "+v"(kbuf[j].y));
-#endif
             }
         }
 #pragma unroll
         for (int co = 0; co < K1; co++) {
             dft8<true>(out[co]);
-#ifndef TFHE_ABL_X2
             x2_store(lane, out[co], xch);
             WAVE_LDS_FENCE();
             x2_load(lane, out[co], xch);
-#endif
             {
                 cplx t2[8];
 #pragma unroll
-#ifdef TFHE_ABL_TW2
-                for (int q = 1; q < 8; q++) t2[q] = tw1f[q];
-#else
                 for (int q = 1; q < 8; q++) t2[q] = TW2REG ? tw2r[q] : tw2_lds[q * 8 + (lane & 7)];
-#endif
 #pragma unroll
                 for (int q = 1; q < 8; q++) out[co][q] = cmulc(out[co][q], t2[q]);
             }
             dft8<true>(out[co]);
             WAVE_LDS_FENCE();
-#ifndef TFHE_ABL_X1
             x1_store_b(lane, out[co], xch);
             WAVE_LDS_FENCE();
             x1_load_a(lane, out[co], xch);
-#endif
             WAVE_LDS_FENCE();
 #pragma unroll
             for (int q = 0; q < 8; q++) out[co][q] = cmulc(out[co][q], tw1f[q]);
@@ -537,10 +485,7 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
     constexpr int NP = 2;
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
     constexpr int OTHER = 1 - PARTY;
-#ifndef TFHE_MK_KPN
-#define TFHE_MK_KPN 2
-#endif
-    constexpr int MKPN = TFHE_MK_KPN;
+    constexpr int MKPN = 2;
     const int beta = P.g.log2_base;
     int a_next = load_uniform_i32(bara + PARTY * P.n) & (2 * kN - 1);
     STAMP_DECL;
@@ -1546,7 +1491,7 @@ __global__ __launch_bounds__(64 * RW, 2) void blind_rotate_kernel_k2(BrArgs P)
 // ---- k = 2, small batches and the last round of a large one: THREE waves per blind rotation (round 5) ------------------
 // blind_rotate_kernel_k2 runs a rotation on one wave: 3 L forward and 3 inverse transforms per CMUX step back to back, and a
 // round of up to four rotations per CU — one wave per SIMD — costs the same 6.8 - 7.3 ms however few rotations it holds
-// (kK2RoundCost, tfhe_engine.hip): a batch of 4096 = 16 per CU pays 7.3 ms for its last four.  Here wave c owns accumulator
+// (kK2RoundCost, engine_dispatch.hip): a batch of 4096 = 16 per CU pays 7.3 ms for its last four.  Here wave c owns accumulator
 // polynomial c (blind_rotate_kernel_w2's structure with three polynomials): it rotates and decomposes only its own polynomial,
 // runs its L forward transforms, multiplies each spectrum into partial sums of all three output components, keeps its own
 // and hands the other two over — the one for wave c + 1 through its transposition buffer, which changes hands (after the
@@ -1761,14 +1706,11 @@ template <int L, bool MARGIN = false, int RW = 2>
 __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048Args P)
 {
     constexpr int K1 = 2;
-#ifndef TFHE_N2048X_KPN
-#define TFHE_N2048X_KPN 2
-#endif
     // The first KPN values of the co = 0 key chunk are requested inside the transform, between the store and the load of its
     // second transposition (x[] is dead there; a chunk requested before the transform spills into the loop: 71.7 ms), the
     // rest after the transform: the L2 round trip then overlaps the last radix-8 pass.  Round 3, one device, 4096 rotations of
     // config 4b: 0: 54.2 ms, 1: 49.8, 2: 48.0, 3: 49.9, 4: 49.3-50.1, 6: 48.6-49.2, 8: 49.4-50.4
-    constexpr int KPN = TFHE_N2048X_KPN;
+    constexpr int KPN = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
@@ -2081,7 +2023,7 @@ __global__ __launch_bounds__(64, 1) void blind_rotate_kernel_general(BrGenArgs P
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
 }
 
-#ifndef TFHE_KERNEL_TEMPLATES_ONLY     // (the translation units that only instantiate kernel templates — mk_g2_*.hip — leave these out)
+#ifdef TFHE_EMIT_KEYPREP_KERNELS       // (defined by engine_keys.hip, the one translation unit that launches them)
 // key preparation for N = 2048: Int32 polynomial -> [wave][8][64] spectra scaled by 1/1024
 __global__ __launch_bounds__(128) void bk_prepare_kernel_n2048(const int32_t *__restrict__ bk_i32, cplx *__restrict__ out,
                                                              const cplx *__restrict__ tw1f2, const cplx *__restrict__ tw2)
@@ -2223,4 +2165,4 @@ __global__ __launch_bounds__(64) void bk_permute_c128_kernel(const cplx *__restr
         out[q * kM + k2 * 64 + lane] = mk(v.x * s, v.y * s);
     }
 }
-#endif  // TFHE_KERNEL_TEMPLATES_ONLY
+#endif  // TFHE_EMIT_KEYPREP_KERNELS

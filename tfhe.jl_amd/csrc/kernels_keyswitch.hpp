@@ -26,6 +26,7 @@ struct KsArgs {
 
 constexpr int KS1_WPT = 4;  // words per thread: a workgroup covers 1024 output words
 
+#ifdef TFHE_EMIT_KEYSWITCH_KERNELS     // (defined by engine_dispatch.hip, the one translation unit that launches them)
 __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
 {
     constexpr int WPT = KS1_WPT;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(KsArgs P)
         }
     }
 }
+#endif  // TFHE_EMIT_KEYSWITCH_KERNELS
 
 // ---- keyswitch v3 ---------------------------------------------------------------------------------
 // Work decomposition: (tile of KS3_G samples) x (slice of kN/KS3_SLICES mask words) x (chunk of 512
@@ -101,6 +103,7 @@ struct Ks3Args {
     int32_t in_stride, in_off, in_b, out_stride, out_off, out_b;
 };
 
+#ifdef TFHE_EMIT_KEYSWITCH_KERNELS
 __global__ void ks3_init_kernel(Ks3Args P)
 {
     const int g = blockIdx.x;
@@ -114,9 +117,11 @@ __global__ void ks3_init_kernel(Ks3Args P)
         o[P.out_b] = (int32_t)b;
     }
 }
+#endif  // TFHE_EMIT_KEYSWITCH_KERNELS
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef TFHE_EMIT_KEYSWITCH_KERNELS
 __global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
 {
     constexpr int G = KS3_G;
@@ -205,6 +210,7 @@ __global__ __launch_bounds__(128, 2) void keyswitch_kernel_v3(Ks3Args P)
         }
     }
 }
+#endif  // TFHE_EMIT_KEYSWITCH_KERNELS
 
 // ---- keyswitch v4: int8 MFMA ------------------------------------------------------------------------
 // out[g][w] = b_g [w == n] - sum_{i,j} KS[i][j][d(g,i,j)][w]   (keyswitch.jl:45-80, no row for digit 0)
@@ -247,6 +253,7 @@ __host__ __device__ inline int32_t signed_byte_plane(uint32_t v, int plane)
     return s;
 }
 
+#ifdef TFHE_EMIT_KEYPREP_KERNELS       // (defined by engine_keys.hip)
 // key preparation: canonical Int32 [kN][8][3][n+1] -> B fragments
 __global__ void ks4_prepare_kernel(const int32_t *__restrict__ ks, i32x4 *__restrict__ bmat, int n, int kN, int wtiles)
 {
@@ -272,7 +279,9 @@ __global__ void ks4_prepare_kernel(const int32_t *__restrict__ ks, i32x4 *__rest
     }
     bmat[idx] = frag;
 }
+#endif  // TFHE_EMIT_KEYPREP_KERNELS
 
+#ifdef TFHE_EMIT_KEYSWITCH_KERNELS
 // Rounded mask words a_i + 2^15 (keyswitch.jl:58-59; MUX: sum of two extracted samples, gates.jl:174) transposed
 // from the sample-major extracted rows into abar_t[i/4][sample] = 4 consecutive words: the MFMA kernel then reads
 // one aligned, fully coalesced 16 bytes per sample and stage instead of scattered 4-byte loads.
@@ -408,4 +417,5 @@ __global__ __launch_bounds__(256, 2) void keyswitch_kernel_v4(Ks4Args P)
             }
         }
 }
+#endif  // TFHE_EMIT_KEYSWITCH_KERNELS
 

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64 * RW, 3) void blind_rotate_kernel_n512(N512Args 
     if (lane == 0) ext[kN5] = acc_lds[kImg5 + kMir];
 }
 
+#ifdef TFHE_EMIT_KEYPREP_KERNELS       // (defined by engine_keys.hip, the one translation unit that launches them)
 // key preparation: Int32 polynomial -> spectrum in the kernel's order, scaled 1/M (forward_transform.(bk), bootstrap.jl:12)
 __global__ __launch_bounds__(64) void bk_prepare_kernel_n512(const int32_t *__restrict__ polys, cplx *__restrict__ out, const cplx *__restrict__ tw1,
                                                             const cplx *__restrict__ tw2q, const cplx *__restrict__ tw3q)
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(64) void bk_permute_c128_kernel_n512(const cplx *__
         out[q * kM5 + q4 * 64 + lane] = mk(v.x * s, v.y * s);
     }
 }
+#endif  // TFHE_EMIT_KEYPREP_KERNELS
 
 // ---- N = 512, small and medium batches: TWO waves per rotation (blind_rotate_kernel_w2's structure at this degree) ------------------
 // One wave per rotation leaves a CU's SIMDs idle below 12 rotations per CU and makes a single gate 500 x (4 forward + 2 inverse

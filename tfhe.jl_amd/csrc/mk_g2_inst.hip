@@ -1,5 +1,4 @@
 // One instantiation of mk_blind_rotate_kernel_g2 and its launcher: -DG2_P=<parties> -DG2_L=<l> -DG2_DG=<0|1> -DG2_RW=<2|4> -DG2_AL=<0|1> (Makefile).
-#define TFHE_KERNEL_TEMPLATES_ONLY
 #include "mk_g2_launch.hpp"
 
 #define G2_PASTE_(P, L, DG, RW, AL) TFHE_G2_LAUNCHER(P, L, DG, RW, AL)

@@ -23,6 +23,20 @@ class SchemeParameters:
         return (self.lwe_size, self.tlwe_polynomial_degree, self.tlwe_mask_size, self.bs_decomp_length,
                 self.bs_log2_base, self.ks_decomp_length, self.ks_log2_base, self.max_parties)
 
+    def exactness(self):
+        """(exact_domain, log2 of the worst-case pre-rounding magnitude, predicted rounding margin): is this set inside what a
+        Float64 transform computes exactly?  The host-side statement of what tfhe_ctx_create decides (csrc/engine_context.hip:
+        exactness_class; tfhe_get_option "exact_domain" / "exact_bound_log2_x1000" / "exact_margin_x1e6") — the reference warns
+        about the same limit (polynomials.jl:135-144).  2 = exact for ANY Int32 key words, 1 = exact for every real (uniform) key,
+        0 = outside.  Depends on (N, k or max_parties, l, beta) only: the engine-independent criterion tests/fuzz_params.py skips by."""
+        products = (self.max_parties + 1 if self.max_parties > 1 else self.tlwe_mask_size + 1) * self.bs_decomp_length
+        N, beta = self.tlwe_polynomial_degree, self.bs_log2_base
+        bound_log2 = math.log2(products * N) + (beta - 1) + 31
+        rms = math.sqrt(products * N) * 2.0 ** (beta + 32) / 12.0
+        margin = 4.0 * 2.0 ** -53 * rms * max(1.0, math.log2(N / 2))
+        ok = margin < 0.25 and 8.0 * rms < 2.0 ** 51
+        return (0 if not ok else 2 if bound_log2 < 51.0 else 1), bound_log2, margin
+
 
 def tfhe_parameters_80(tlwe_mask_size: int = 1) -> SchemeParameters:
     """~80 bits of security (api.jl:30-45)."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction histogram of one kernel in tfhe.jl_amd/build/tfhe_engine.s (make -C tfhe.jl_amd/csrc asm).
+"""Instruction histogram of one kernel in tfhe.jl_amd/build/engine_dispatch.s (make -C tfhe.jl_amd/csrc asm).
 
 usage: tools/asm_hist.py <demangled-name substring> [--file x.s] [--ops] [--dump A B]
 Prints, for the whole kernel body and for every basic block that ends in a backward branch (a loop body as the
@@ -10,7 +10,7 @@ import re
 import subprocess
 import sys
 
-PATH = "tfhe.jl_amd/build/tfhe_engine.s"
+PATH = "tfhe.jl_amd/build/engine_dispatch.s"      # (multi-key kernels: engine_multikey.s)
 
 
 def classify(op):
