@@ -44,6 +44,18 @@ export GpuCloudKey, GpuMKCloudKey, GpuLweArray, gates_batch, gates_batch_async, 
 # the shared library as this repository builds it (make -C tfhe.jl_amd/csrc), or wherever TFHE_MI355X_LIB points
 const LIB = get(ENV, "TFHE_MI355X_LIB", joinpath(@__DIR__, "..", "..", "..", "tfhe.jl_amd", "lib", "libtfhe_mi355x.so"))
 
+# ABI check at load time (include/tfhe_mi355x.h: TFHE_MI355X_ABI_VERSION).  A NEGATIVE answer is a development build of the
+# library (-DTFHE_EXPERIMENT, csrc/experiment.hpp: in-kernel stamps, environment-variable overrides): refused unless the user
+# asked for it.
+const ABI_VERSION = Int32(7)
+function __init__()
+    v = ccall((:tfhe_abi_version, LIB), Int32, ())
+    if v < 0 && get(ENV, "TFHE_MI355X_ALLOW_EXPERIMENT", "") == ""
+        error("$LIB is a development build (ABI version $v): set TFHE_MI355X_ALLOW_EXPERIMENT=1 to load it knowingly")
+    end
+    abs(v) == ABI_VERSION || error("$LIB has ABI version $v, this package needs $ABI_VERSION: rebuild it (make -C tfhe.jl_amd/csrc)")
+end
+
 # include/tfhe_mi355x.h: struct tfhe_params
 struct TfheParams
     n::Int32; N::Int32; k::Int32; bs_l::Int32; bs_log2_base::Int32
@@ -96,7 +108,20 @@ function create_context(p::SchemeParameters, devices)
               tp, ids, Int32(length(ids)), ctxref)
     end
     check(Ptr{Cvoid}(C_NULL), rc)
+    warn_if_inexact(ctxref[], p)
     ctxref[]
+end
+
+# tfhe_get_option "exact_domain" (ABI v7): 0 = the parameter set is outside what a Float64 transform computes exactly — the
+# reference warns about the same limit (src/polynomials.jl:135-144); said once per parameter set
+const WARNED_INEXACT = Set{Any}()
+function warn_if_inexact(ctx::Ptr{Cvoid}, p::SchemeParameters)
+    opt(name) = (v = Ref{Int64}(0); ccall((:tfhe_get_option, LIB), Int32, (Ptr{Cvoid}, Cstring, Ref{Int64}), ctx, name, v) == 0 ? v[] : Int64(-1))
+    opt("exact_domain") == 0 || return
+    key = (p.tlwe_polynomial_degree, p.tlwe_mask_size, p.bs_decomp_length, p.bs_log2_base, p.max_parties)
+    key in WARNED_INEXACT && return
+    push!(WARNED_INEXACT, key)
+    @warn "TFHE parameter set is outside the Float64 exactness domain: result words may differ from the exact negacyclic product" predicted_rounding_margin = opt("exact_margin_x1e6") / 1e6 log2_worst_case_magnitude = opt("exact_bound_log2_x1000") / 1e3
 end
 
 # KeyswitchKey: key[h, j, i]::LweSample (src/keyswitch.jl:12,35-38) -> Int32 [kN][t][base-1][n+1] (C order)
@@ -394,12 +419,17 @@ function gates_batch_async(gck::GpuCloudKey, opcodes::Vector{UInt8}, xs, ys=noth
     t
 end
 
+# Runs as a finalizer: it cannot take the context's lock, and another task may be inside a gate call on the same context at
+# this very moment.  tfhe_ctx_synchronize (ABI v7) is the one entry point made for that: it takes no ownership of the context,
+# touches none of its state and returns once everything queued so far — this batch's copies included — has completed.  The
+# page-locked buffers go back ONLY after it returned TFHE_OK: on any other answer they are leaked rather than freed under a DMA
+# that may still be running.  (Until ABI v6 this called tfhe_gates_batch_wait, which the library's one-caller-at-a-time guard
+# answered with TFHE_ERR_STATE at once while another task was inside a call — and the buffers were freed regardless.)
 function abandon!(t::PendingGates)
     t.done && return nothing
-    if t.key.ctx != C_NULL
-        ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)    # the DMA is over after this, error or not
-    end
-    foreach(release_pinned, t.buffers)
+    drained = t.key.ctx == C_NULL ||      # (the context is gone: tfhe_ctx_destroy synchronised its streams)
+              ccall((:tfhe_ctx_synchronize, LIB), Int32, (Ptr{Cvoid},), t.key.ctx) == 0
+    drained && foreach(release_pinned, t.buffers)
     empty!(t.buffers)
     t.done = true
     nothing
@@ -408,14 +438,11 @@ end
 function Base.fetch(t::PendingGates)
     t.done && error("PendingGates: already fetched")
     rc = @locked t.key.ctx ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, t.ticket)
-    if rc != 0
-        # a failed wait says nothing about the copies still in flight: wait on both streams before the buffers go back
-        for other in Int32(0):Int32(1)
-            ccall((:tfhe_gates_batch_wait, LIB), Int32, (Ptr{Cvoid}, Int32), t.key.ctx, other)
-        end
-    end
+    # a failed wait says nothing about the copies still in flight: drain the context (tfhe_ctx_synchronize needs no lock and
+    # cannot be refused) before the buffers go back; if even that fails they are leaked, not freed under a live DMA
+    drained = rc == 0 || ccall((:tfhe_ctx_synchronize, LIB), Int32, (Ptr{Cvoid},), t.key.ctx) == 0
     res = rc == 0 ? unflatten(copy(t.out), LweParams(t.key.params.lwe_size)) : nothing
-    foreach(release_pinned, t.buffers)
+    drained && foreach(release_pinned, t.buffers)
     empty!(t.buffers)
     t.done = true
     check(t.key.ctx, rc)

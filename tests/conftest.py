@@ -14,6 +14,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def device_count():
+    """HIP devices visible to this process (0 without the library or without a GPU; counting does not initialise a device)."""
+    try:
+        import tfhe_jl_amd as t
+        return max(0, t._lib.load().tfhe_device_count())
+    except Exception:
+        return 0
+
+
+# Every test of a multi-device context (tfhe_ctx_create_multi) runs twice: on {0, 0} — two device contexts sharing the one GPU
+# of the box, which is all a one-GPU lease can execute — and on {0, 1}, two DIFFERENT devices: peer access, hipMemcpyPeerAsync
+# between devices, events waited for across devices, RCCL between two GPUs.  The second variant is collected everywhere and
+# skipped with this reason until a box shows two devices (round-5 verdict: "nothing has ever executed on two distinct devices,
+# and no existing test would").
+two_gpus = pytest.mark.skipif(device_count() < 2, reason=f"needs two HIP devices, this process sees {device_count()} (the {{0, 0}} variant of the same test ran)")
+DEVICE_PAIRS = [pytest.param([0, 0], id="devices00"), pytest.param([0, 1], id="devices01", marks=two_gpus)]
+
+
 def have_gpu():
     """True if the HIP library loads and sees a device (counting devices does not initialise one)."""
     try:

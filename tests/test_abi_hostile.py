@@ -8,6 +8,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import DEVICE_PAIRS
+
 
 @pytest.mark.gpu
 def test_hostile_arguments_return_errors(tfhe, orc, keys80):
@@ -59,6 +61,7 @@ def test_hostile_arguments_return_errors(tfhe, orc, keys80):
     expect_error("mk_gate_nand on single-key ctx", lib.tfhe_mk_gate_nand_batch(h, p(x), p(y), p(out), 3))
     # wire table
     idx = np.array([0, 1, 2], np.int32)
+    assert lib.tfhe_wires_alloc(h, 0) == 0          # (the session's engine may carry a table from an earlier test: 0 frees it)
     expect_error("gates_level without a table", lib.tfhe_gates_level(h, p(ops), p(idx), p(idx), NULL, p(idx), 3))
     expect_error("wires_upload without a table", lib.tfhe_wires_upload(h, 0, 3, p(x)))
     expect_error("wires_alloc negative", lib.tfhe_wires_alloc(h, -4))
@@ -114,7 +117,8 @@ def test_hostile_arguments_return_errors(tfhe, orc, keys80):
 
 
 @pytest.mark.gpu
-def test_hostile_arguments_multi_key_and_multi_device(tfhe, orc, keys80):
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_hostile_arguments_multi_key_and_multi_device(tfhe, orc, keys80, devs):
     """The same on a multi-key context (single-key entry points refused, NULL / negative arguments) and on a {0, 0} multi-device
     context (wire-table calls with indices outside the table, device-pointer calls)."""
     from tfhe_jl_amd import _lib as L
@@ -156,13 +160,14 @@ def test_hostile_arguments_multi_key_and_multi_device(tfhe, orc, keys80):
     assert np.array_equal(eng.mk_gate_nand(x, y), o.mk_gate_nand(x, y, nthreads=4))       # still sound
     # {0, 0} multi-device context
     K = keys80
-    m = K.ck.engine([0, 0])
+    m = K.ck.engine(devs)
     hm = m._h
     n1 = K.params.lwe_size + 1
     a = tfhe.encrypt(K.rng, K.sk, [True, False, True]).data
     idx = np.array([0, 1, 2], np.int32)
     ops3 = np.zeros(3, np.uint8)
     o3 = np.zeros((3, n1), np.int32)
+    assert lib.tfhe_wires_alloc(hm, 0) == 0
     expect_error("multi: gates_level without a table", lib.tfhe_gates_level(hm, p(ops3), p(idx), p(idx), NULL, p(idx), 3))
     assert lib.tfhe_wires_alloc(hm, 8) == 0
     expect_error("multi: wires_upload past the end", lib.tfhe_wires_upload(hm, 7, 3, p(a)))

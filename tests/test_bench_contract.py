@@ -131,3 +131,63 @@ def test_committed_profile_matches_the_sources_and_the_instruction_budget():
         v3 = [v for k, v in d.items() if "blind_rotate_kernel_v3<2, 8, true, false, 4>" in k]
         assert v3, f
         assert v3[0]["valu_insts_per_launch"] <= 4.28e9, (f, v3[0]["valu_insts_per_launch"])
+
+
+# ---- two DIFFERENT devices: collected everywhere, skipped until a box shows two (tests/conftest.py: two_gpus) ---------------------
+from conftest import two_gpus  # noqa: E402
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFHE_BENCH_SHARE_GPU", "TFHE_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    return env
+
+
+def _check_two_gpu_line(d, gates=None):
+    assert d["n_gpus"] == 2 and d["outputs_decrypt_correctly"] is True
+    assert d["gather_matches_local_shard"] is True and d["gather_matches_every_ranks_checksum"] is True and d["every_rank_decrypts"] is True
+    g = d["config"]["result_gather"]
+    # real RCCL between two GPUs: the point-to-point gather to rank 0, or — if this RCCL build rejects `gather` — the all_gather
+    # fallback, named as such (bench.py: ResultGather)
+    assert g.startswith("rccl ") and ("gather to rank 0" in g) and "rehearsal" not in g, g
+    if gates:
+        assert abs(d["value"] - 2 * gates * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@two_gpus
+def test_bench_two_gpus_self_spawned_real_rccl():
+    """`python bench.py --gpus 2` on a box with two GPUs: one rank per device, RCCL for the barrier, the max-reduce and the result
+    gather — the first execution of bench.py's collective path between two different devices."""
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gates", "300"], _clean_env())
+    assert d["scaling"] == "weak"
+    _check_two_gpu_line(d, 300)
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "mixed"], _clean_env())
+    assert d["scaling"] == "strong"
+    _check_two_gpu_line(d)
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@two_gpus
+def test_bench_two_gpus_under_the_drivers_launcher():
+    """The driver's own launch line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`) on two GPUs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = _one_json_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gates", "512"], _clean_env())
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
+    _check_two_gpu_line(d, 512)
+
+
+@pytest.mark.gpu
+@two_gpus
+def test_bench_fanout_on_two_gpus():
+    """`--fanout --gpus 2`: ONE process, one multi-device context on devices {0, 1} (tfhe_ctx_create_multi with distinct ids)."""
+    d = _one_json_line([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--fanout", "--steps", "2", "--warmup", "1", "--gates", "300"], _clean_env())
+    assert d["n_gpus"] == 2 and d["outputs_decrypt_correctly"] is True and "multi-device context" in d["config"]["launch"]
+    assert d["fanout_matches_one_device"] is True
+    assert d["roofline"]["units_per_launch"] == 600 and "host buffers" in d["config"]["inputs"]

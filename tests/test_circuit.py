@@ -4,6 +4,8 @@ oracle evaluating the same gates one at a time."""
 import numpy as np
 import pytest
 
+from conftest import DEVICE_PAIRS
+
 
 def tutorial_min_circuit(tfhe, nbits=16):
     """examples/tutorial.jl:42-62: carry = MUX(XNOR(a_i, b_i), carry, a_i) over the bits, then out_i = MUX(carry, b_i, a_i)."""
@@ -162,7 +164,8 @@ def test_log_depth_minimum_circuit_on_device(tfhe, orc, keys80):
 
 
 @pytest.mark.gpu
-def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_circuits_on_a_multi_device_context(tfhe, orc, keys80, devs):
     """A multi-device context ({0, 0} on the one-GPU box: two device contexts, two replicas of the wire table) runs narrow
     levels on its first device and shards wide ones (option level_split_min, lowered here so that the 17- and 16-gate levels
     of the tutorial circuit split).  A device fetches the operand rows whose current value another device holds right before it
@@ -175,7 +178,8 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
     K = keys80
     bits = [(2017 >> i) & 1 == 1 for i in range(16)] + [(42 >> i) & 1 == 1 for i in range(16)]
     enc = tfhe.encrypt(K.rng, K.sk, bits)
-    multi = K.ck.engine([0, 0])
+    multi = K.ck.engine(devs)
+    print(f"devices {devs}: device-to-device copies allowed between {multi.get_option('peer_pairs')} of {len(devs) * (len(devs) - 1)} ordered pairs")
     for circ in (tutorial_min_circuit(tfhe, 16), encrypted_minimum_circuit(16, log_depth=True)):
         want = circ.run(K.ck, enc).data
         want_all = K.ck.engine(0).wires_gather(np.arange(circ.num_wires, dtype=np.int32))
@@ -184,7 +188,7 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
             assert multi.get_option("level_exchange") == exchange
             for split in (4096, 8, 2):        # never split at these sizes / only the 16-gate levels / everything but single gates
                 multi.set_option("level_split_min", split)
-                got = circ.run(K.ck, enc, device=[0, 0]).data
+                got = circ.run(K.ck, enc, device=devs).data
                 assert np.array_equal(got, want), (exchange, split)
                 # the last level of both circuits is 16 parallel MUXes = 32 rotations: sharded over both device contexts iff the
                 # threshold allows it (tfhe_last_device_count, ABI v5)
@@ -201,7 +205,7 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
     # intermediate wires are coherent too: every wire of the table, read back from the first device
     circ = tutorial_min_circuit(tfhe, 16)
     multi.set_option("level_split_min", 8)
-    circ.run(K.ck, enc, device=[0, 0])
+    circ.run(K.ck, enc, device=devs)
     all_multi = multi.wires_gather(np.arange(circ.num_wires, dtype=np.int32))
     circ.run(K.ck, enc)
     assert np.array_equal(all_multi, K.ck.engine(0).wires_gather(np.arange(circ.num_wires, dtype=np.int32)))
@@ -209,11 +213,12 @@ def test_circuits_on_a_multi_device_context(tfhe, orc, keys80):
 
 
 @pytest.mark.gpu
-def test_streamed_batches_on_a_multi_device_context(tfhe, keys80, orc):
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_streamed_batches_on_a_multi_device_context(tfhe, keys80, orc, devs):
     """tfhe_gates_batch_submit / _wait on a multi-device context: every device takes its shard as a submit of its own (two
     batches in flight per device); results equal the blocking call's and the oracle's on a sample."""
     K = keys80
-    multi = K.ck.engine([0, 0])
+    multi = K.ck.engine(devs)
     rng = np.random.default_rng(31)
     names = ["NAND", "AND", "OR", "XOR", "MUX"]
     jobs = []

@@ -7,6 +7,8 @@ BASELINE configs 4a / 4b / 5 at their stated batch sizes are in this file too.""
 import numpy as np
 import pytest
 
+from conftest import DEVICE_PAIRS
+
 pytestmark = pytest.mark.gpu
 
 MU = 2**29
@@ -432,20 +434,23 @@ def test_config5_mk_two_party_1024(tfhe, orc):
     eng.set_option("mk_general", 1)                 # the any-party kernel gives the same words
     assert np.array_equal(eng.mk_gate_nand(x[:96], y[:96]), got[:96]) and eng.last_kernel_name() == "mk_blind_rotate_kernel_general(P=2,L=4)"
     eng.set_option("mk_general", 0)
-    # the fan-out context (two device contexts on this one GPU) gives the same words
-    e2 = ck.engine([0, 0])
-    assert e2.device_count() == 2
-    assert np.array_equal(e2.mk_gate_nand(x[:65], y[:65]), got[:65])
+    # the fan-out context (two device contexts on this one GPU; on two different GPUs where the box has them) gives the same words
+    from conftest import device_count
+    for devs in ([0, 0], [0, 1])[:2 if device_count() >= 2 else 1]:
+        e2 = ck.engine(devs)
+        assert e2.device_count() == 2
+        assert np.array_equal(e2.mk_gate_nand(x[:65], y[:65]), got[:65]), devs
     ck.close()
 
 
 # ---- the multi-device context behind the ABI ----------------------------------------------------------
-def test_multi_device_context_equals_single(tfhe, orc, keys80):
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_multi_device_context_equals_single(tfhe, orc, keys80, devs):
     """tfhe_ctx_create_multi with device_ids = {0, 0}: keys replicated, a mixed batch split into rotation-balanced
     shards run concurrently, results written into the caller's buffer — identical to the one-device context."""
     K = keys80
     e1 = K.ck.engine(0)
-    e2 = K.ck.engine([0, 0])
+    e2 = K.ck.engine(devs)
     assert e2.device_count() == 2 and e1.device_count() == 1
     rng = np.random.default_rng(8)
     names = ["NAND", "AND", "OR", "XOR", "MUX", "NOT", "CONST1", "COPY"]

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import philox_ref as ph
+from conftest import DEVICE_PAIRS
 
 
 def test_philox4x32_10_known_answers():
@@ -174,8 +175,10 @@ def test_device_key_noise_statistics(tfhe):
 
 
 @pytest.mark.gpu
-def test_device_keygen_on_a_multi_device_context(tfhe):
-    """A fan-out context ({0, 0} on the one-GPU box) generates on its first device and replicates: same key, same gates."""
+@pytest.mark.parametrize("devs", DEVICE_PAIRS)
+def test_device_keygen_on_a_multi_device_context(tfhe, devs):
+    """A fan-out context ({0, 0} on the one-GPU box; {0, 1}: the second device takes the key through a host copy) generates on its
+    first device and replicates: same key, same gates."""
     p = tfhe.tfhe_parameters_80()
     rng = np.random.default_rng(5)
     sk = tfhe.SecretKey(rng, p)
@@ -183,7 +186,7 @@ def test_device_keygen_on_a_multi_device_context(tfhe):
     fixed = [11, 22, 33, 44]                 # (the noise key otherwise comes from os.urandom, whatever `rng` is)
     ck1 = tfhe.CloudKey(rng, sk, keygen="device", device=0, noise_seed=fixed)
     rng.bit_generator.state = st
-    ck2 = tfhe.CloudKey(rng, sk, keygen="device", device=[0, 0], noise_seed=fixed)
+    ck2 = tfhe.CloudKey(rng, sk, keygen="device", device=devs, noise_seed=fixed)
     rng.bit_generator.state = st
     ck3 = tfhe.CloudKey(rng, sk, keygen="device", device=0)
     assert not np.array_equal(ck1.bootstrap_key, ck3.bootstrap_key)               # a fresh noise key from the OS every time
@@ -194,6 +197,6 @@ def test_device_keygen_on_a_multi_device_context(tfhe):
     bits = rng.integers(0, 2, (2, 40)).astype(bool)
     x, y = tfhe.encrypt(rng, sk, bits[0]).data, tfhe.encrypt(rng, sk, bits[1]).data
     ops = np.zeros(40, np.uint8)
-    a, b = ck1.engine(0).gates(ops, x, y), ck2.engine([0, 0]).gates(ops, x, y)
+    a, b = ck1.engine(0).gates(ops, x, y), ck2.engine(devs).gates(ops, x, y)
     assert np.array_equal(a, b) and np.array_equal(tfhe.decrypt(sk, a), ~(bits[0] & bits[1]))
     ck1.close(); ck2.close()

@@ -344,19 +344,26 @@ ScopeExit<F> on_exit(F f) { return ScopeExit<F>{f}; }
 template <typename F>
 static int32_t fan_out(tfhe_ctx *c, const std::vector<int> &which, F &&fn)
 {
+    // Everything that can throw is allocated BEFORE the first thread exists, and every shard — on a worker thread or on the
+    // calling one — turns an exception into its status: a std::thread that is still joinable when an exception unwinds this frame
+    // would end the process (std::terminate), as would an exception that left a thread's function.
     std::vector<int32_t> rcs(which.size(), TFHE_OK);
     std::vector<std::thread> th;
     std::vector<size_t> inline_ones;          // kids whose thread could not be started (thread / process limit): run here, in turn
+    th.reserve(which.size());
+    inline_ones.reserve(which.size());
+    auto shard = [&](size_t i) noexcept {
+        try { rcs[i] = fn(which[i]); } catch (...) { rcs[i] = abi_caught(c->kids[(size_t)which[i]], "fan-out shard"); }
+    };
     for (size_t i = 1; i < which.size(); i++) {
         try {
-            // (an exception that left a thread's function would end the process: the worker reports it as a status)
-            th.emplace_back([&, i] { try { rcs[i] = fn(which[i]); } catch (...) { rcs[i] = abi_caught(c->kids[(size_t)which[i]], "fan-out worker"); } });
-        } catch (const std::exception &) {    // the thread could not be started (std::system_error): this shard runs on the caller's thread
+            th.emplace_back([&shard, i] { shard(i); });
+        } catch (...) {                       // the thread could not be started (std::system_error): this shard runs on the caller's thread
             inline_ones.push_back(i);
         }
     }
-    if (!which.empty()) rcs[0] = fn(which[0]);
-    for (size_t i : inline_ones) rcs[i] = fn(which[i]);
+    if (!which.empty()) shard(0);
+    for (size_t i : inline_ones) shard(i);
     for (auto &t : th) t.join();
     std::fill(c->kid_ran.begin(), c->kid_ran.end(), 0);
     for (int k : which) c->kid_ran[(size_t)k] = 1;

@@ -217,6 +217,14 @@ int32_t tfhe_get_option(tfhe_ctx *c, const char *name, int64_t *value) try
     if (!strcmp(name, "exact_bound_log2_x1000")) { *value = (int64_t)std::llround(c->exact_bound_log2 * 1000.0); return TFHE_OK; }
     if (!strcmp(name, "exact_margin_x1e6")) { *value = (int64_t)std::llround(c->exact_margin * 1e6); return TFHE_OK; }
     if (!strcmp(name, "debug_fail_alloc_after")) { *value = g_fail_alloc_countdown.load(); return TFHE_OK; }
+    if (c->multi() && !strcmp(name, "peer_pairs")) {      // read-only: ordered pairs of DIFFERENT device contexts of this context that copy device to device
+        int64_t n = 0;
+        const size_t nk = c->kids.size();
+        for (size_t a = 0; a < nk; a++)
+            for (size_t b = 0; b < nk; b++) n += (a != b && c->peer_ok[a * nk + b]) ? 1 : 0;
+        *value = n;
+        return TFHE_OK;
+    }
     if (c->multi() && strcmp(name, "level_split_min") && strcmp(name, "level_exchange")) {
         const int32_t rc = tfhe_get_option(c->kids[0], name, value);      // set_option gives every device the same value
         if (rc) c->err = c->kids[0]->err;
