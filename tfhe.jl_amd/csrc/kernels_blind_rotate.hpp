@@ -96,6 +96,86 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
+// ---- the register part of the N = 1024 twist in tan form with OPAQUE constants ------------------------------------------------------
+// br_core.hpp's load_digits2t / dft8_fwd_tw with their constants as scalar values the compiler cannot see through (made once per
+// kernel: load_tan16).  A compile-time double that is used with both signs is materialised as two scalar register pairs (+c and -c: the
+// two-operand FMA has no negation modifier); in a kernel at its scalar-register limit that means spills and a worse schedule (the
+// N = 2048 and multi-key kernels lost 16 - 23 % to it in round 5).  An opaque value is negated by the instruction's source modifier.
+__device__ __forceinline__ double opaque_scalar(double v) { asm("" : "+s"(v)); return v; }
+struct Tan16 { double t[5], r0, r1, r3, g0, l, sl, c[5]; };      // twt(1 .. 3); kTwR0, kTwR1, kTwR3, kTwG0, kTwL, kTwSL; twk(1 .. 4) (load_tan16<true>)
+template <bool WITH_COS = false>
+__device__ __forceinline__ Tan16 load_tan16()
+{
+    Tan16 k;
+    k.t[0] = 0.0; k.t[4] = 1.0; k.c[0] = 1.0;
+    if (WITH_COS) { k.c[1] = opaque_scalar(twk(1)); k.c[2] = opaque_scalar(twk(2)); k.c[3] = opaque_scalar(twk(3)); k.c[4] = opaque_scalar(twk(4)); }
+    k.t[1] = opaque_scalar(twt(1)); k.t[2] = opaque_scalar(twt(2)); k.t[3] = opaque_scalar(twt(3));
+    k.r0 = opaque_scalar(kTwR0); k.r1 = opaque_scalar(kTwR1); k.r3 = opaque_scalar(kTwR3);
+    k.g0 = opaque_scalar(kTwG0); k.l = opaque_scalar(kTwL); k.sl = opaque_scalar(kTwSL);
+    return k;
+}
+template <int R>
+__device__ __forceinline__ cplx twist_tan_o(double a, double b, const Tan16 &k)      // twist_tan<R>
+{
+    if (R == 0) return mk(a, -b);
+    if (R == 4) return mk(a - b, -(b + a));
+    const double t = k.t[R < 4 ? R : 8 - R];
+    if (R < 4) return mk(fma_(-t, b, a), -fma_(t, a, b));
+    return mk(fma_(t, a, -b), -fma_(t, b, a));
+}
+__device__ __forceinline__ void load_digits2t_o(const int32_t (&temp)[16], int p, int log2_base, cplx (&u)[8], const Tan16 &k)
+{
+    static_for<0, 8>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        u[R] = twist_tan_o<R>((double)digit2(temp[R], p, log2_base), (double)digit2(temp[R + 8], p, log2_base), k);
+    });
+}
+__device__ __forceinline__ void dft8_fwd_tw_o(cplx (&x)[8], const Tan16 &k)      // dft8_fwd_tw
+{
+    const cplx a0 = axpy(x[0], k.r0, x[4]), a1 = axpy(x[1], k.r1, x[5]), a2 = cadd(x[2], x[6]), a3 = axpy(x[3], k.r3, x[7]);
+    const cplx t0 = axpy(x[0], -k.r0, x[4]), t1 = axpy(x[1], -k.r1, x[5]), t2 = csub(x[2], x[6]), t3 = axpy(x[3], -k.r3, x[7]);
+    const cplx b1 = mk(t1.x + t1.y, t1.y - t1.x);
+    const cplx b2 = mk(t2.y, -t2.x);
+    const cplx b3 = mk(t3.y - t3.x, -(t3.x + t3.y));
+    {
+        const cplx c0 = axpy(a0, k.g0, a2), d0 = axpy(a0, -k.g0, a2), c1 = axpy(a1, k.r1, a3), e = axpy(a1, -k.r1, a3);
+        const cplx d1 = mk(e.y, -e.x);
+        x[0] = axpy(c0, k.l, c1); x[4] = axpy(c0, -k.l, c1); x[2] = axpy(d0, k.l, d1); x[6] = axpy(d0, -k.l, d1);
+    }
+    {
+        const cplx c0 = axpy(t0, k.g0, b2), d0 = axpy(t0, -k.g0, b2), c1 = axpy(b1, k.r1, b3), e = axpy(b1, -k.r1, b3);
+        const cplx d1 = mk(e.y, -e.x);
+        x[1] = axpy(c0, k.sl, c1); x[5] = axpy(c0, -k.sl, c1); x[3] = axpy(d0, k.sl, d1); x[7] = axpy(d0, -k.sl, d1);
+    }
+}
+
+// untwist_add2<MARGIN, true> (br_core.hpp) with the opaque constants: conj(y) e^{-i pi r/16} in tan form, the cosine on the rounding FMA
+template <bool MARGIN>
+__device__ __forceinline__ void untwist_add2_o(const cplx (&y)[8], int32_t (&acc)[16], double *worst, const Tan16 &k)
+{
+    static_for<0, 8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const double t = k.t[r < 4 ? r : 8 - r], c = k.c[r < 4 ? r : 8 - r];
+        double zr, zi;
+        if (r == 0) { zr = y[r].x; zi = y[r].y; }
+        else if (r == 4) { zr = y[r].x - y[r].y; zi = y[r].y + y[r].x; }
+        else if (r < 4) { zr = fma_(-t, y[r].y, y[r].x); zi = fma_(t, y[r].x, y[r].y); }
+        else { zr = fma_(t, y[r].x, -y[r].y); zi = fma_(t, y[r].y, y[r].x); }
+        if (MARGIN) {
+            const double a = frac_dist(zr * c), b = frac_dist(zi * c);
+            if (a > *worst) *worst = a;
+            if (b > *worst) *worst = b;
+        }
+        if (r == 0) {
+            acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_to_torus32(zr));
+            acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_to_torus32(-zi));
+        } else {
+            acc[r] = (int32_t)((uint32_t)acc[r] + (uint32_t)round_scaled_to_torus32(zr, c));
+            acc[r + 8] = (int32_t)((uint32_t)acc[r + 8] + (uint32_t)round_scaled_to_torus32(zi, -c));
+        }
+    });
+}
+
 struct BrArgs {
     DiagArgs diag;
     const int32_t *bara;  // [R][n+1], barb last
@@ -407,10 +487,11 @@ struct MkBrArgs {
 // `mid()` runs between the store and the load of the second transposition, when x[] is dead: the place to request global
 // data (32 registers are free there) that the caller needs right after the transform.
 // TW: x[] comes from load_digits2t (the register part of the twist in tan form; its cosines ride on the first butterfly)
-template <bool TW = false, typename MID>
+// PRE: the caller has run the first radix-8 pass itself (dft8_fwd_scaled_in)
+template <bool TW = false, bool PRE = false, typename MID>
 __device__ __forceinline__ void fft_fwd_wave_mid(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch, MID &&mid)
 {
-    if (TW) dft8_fwd_tw(x); else dft8<false>(x);
+    if (PRE) { } else if (TW) dft8_fwd_tw(x); else dft8<false>(x);
 #pragma unroll
     for (int q = 0; q < 8; q++) x[q] = cmul(x[q], tw1f[q]);
     x1_store_a(lane, x, xch);
@@ -477,10 +558,10 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
 // wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
 // polynomials.  Two barriers per step (hand-off written / accumulator updated).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
 // reuses the transposition buffers).  Same words as the any-party kernel (round 3's one-wave 2-party kernel is gone).  L must be even.
-template <int L, int PARTY, int WV, bool MARGIN>
+template <int L, int PARTY, int WV, bool MARGIN, int TAN>
 __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                 cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
-                                                int32_t xormask, double &worst)
+                                                int32_t xormask, double &worst, const Tan16 &tk)
 {
     constexpr int NP = 2;
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
@@ -530,10 +611,11 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
 #pragma unroll
                 for (int k2 = 0; k2 < 8; k2++) kpa[k2] = k_party[k2 * 64];
                 cplx x[8];
-                load_digits2(temp, p + 1, beta, x);
+                if constexpr (TAN) { load_digits2t_o(temp, p + 1, beta, x, tk); dft8_fwd_tw_o(x, tk); }
+                else load_digits2(temp, p + 1, beta, x);
                 cplx kbo[8];
                 // (the first values of the second poly are requested inside the transform, where x[] is dead: see blind_rotate_kernel_n2048x)
-                fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch_own, [&]() {
+                fft_fwd_wave_mid<false, (TAN != 0)>(lane, x, tw1f, tw2_lds, xch_own, [&]() {
 #pragma unroll
                     for (int k2 = 0; k2 < MKPN; k2++) kbo[k2] = k_body[k2 * 64];
                 });
@@ -588,7 +670,14 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
         STAMP(6);
         auto finish = [&](cplx (&o)[8], int d) {
             fft_inv_wave(lane, o, tw1f, tw2_lds, xch_oth);
-            accumulate_poly<MARGIN, false>(lane, o, acc_lds + d * kImg, &worst);
+            if constexpr (TAN == 2) {
+                int32_t accr[16];
+                load_cur<16>(lane, acc_lds + d * kImg, accr);
+                untwist_add2_o<MARGIN>(o, accr, &worst, tk);
+                store_cur<16>(lane, accr, acc_lds + d * kImg);
+            } else {
+                accumulate_poly<MARGIN, false>(lane, o, acc_lds + d * kImg, &worst);
+            }
         };
         if (WV == 0) { finish(out[0], 0); finish(out[1], 1); }
         else finish(out[NP], NP);
@@ -604,6 +693,9 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
 template <int L, bool MARGIN = false, int RW = 2>
 __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArgs P)
 {
+    // Round 6: the register part of the twist in tan form, forward and inverse, with OPAQUE constants (load_tan16): 16.54 -> 16.28 ms per
+    // 1024 gates on one device (forward only: 16.36).  Round 5 tried the same with compile-time constants and lost 23 % to scalar spills.
+    constexpr int TAN = 2;
     static_assert(L % 2 == 0, "the two waves split the digits evenly");
     constexpr int NP = 2;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
@@ -633,13 +725,15 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     else init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
     __syncthreads();
     wave_priority_begin(P.prio_steps);
+    Tan16 tk;
+    if constexpr (TAN != 0) tk = load_tan16<(TAN == 2)>();
     // party-major double loop (mk_internals.jl:475-476)
     if (wv == 0) {
-        mk2_party_steps<L, 0, 0, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
-        mk2_party_steps<L, 1, 0, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+        mk2_party_steps<L, 0, 0, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
+        mk2_party_steps<L, 1, 0, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
     } else {
-        mk2_party_steps<L, 0, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
-        mk2_party_steps<L, 1, 1, MARGIN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst);
+        mk2_party_steps<L, 0, 1, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
+        mk2_party_steps<L, 1, 1, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
     }
     if (!live) return;
     const int lane_e = lane_id_fresh();
@@ -1643,6 +1737,81 @@ __device__ __forceinline__ cplx fwd_in_2048(double lo, double hi, double s2, dou
 
 constexpr int kImg2 = kMir + kN2;       // one N = 2048 polynomial in LDS: mirror | coefficients (rotate_sub3<32>)
 
+// ---- twists by multiples of pi/32 in tan form ------------------------------------------------------------------------------------
+// e^{-i K pi/32} = (-i)^q cos(phi) (1 - i tan(phi)) with q the multiple of pi/2 nearest to the angle and |phi| = |J| pi/32 <= pi/4: the
+// product by (1 - i tan) is two FMAs, (-i)^q is a swap with signs, and the cosine (0.707 .. 1) is left to ride on an FMA that
+// follows (the first butterfly of the transform, the FMA that adds the rounding constant) — br_core.hpp's twist_tan for the
+// N = 2048 kernel's angles.  Both waves of that kernel (angles R pi/32 and 5 R pi/32), the recombination (4 R pi/32) and the
+// untwist (R pi/32, (R + 8) pi/32) draw on ONE set of constants: tan and cos of j pi/32, j = 1 .. 8.
+__host__ __device__ constexpr double tan_pi32(int j)    // tan(j pi / 32), 0 <= j <= 8
+{
+    constexpr double T[9] = {0.0, 0.0984914033571642530797, 0.198912367379658006913, 0.303346683607342391676, 0.414213562373095048818,
+                             0.534511135950791641078, 0.668178637919298920047, 0.820678790828660330965, 1.0};
+    return T[j];
+}
+struct Oct32 { int q, J; };      // angle K pi/32 = q pi/2 + J pi/32, |J| <= 8
+__host__ __device__ constexpr Oct32 oct32(int K)
+{
+    const int Km = ((K % 64) + 64) % 64, qq = (Km + 7) / 16;
+    return Oct32{qq % 4, Km - 16 * qq};
+}
+__host__ __device__ constexpr int scale32_index(int K) { const int J = oct32(K).J; return J < 0 ? -J : J; }      // the cosine left behind is cos(index pi/32)
+// The constants as OPAQUE scalar values, made once per kernel: a compile-time double that appears with both signs (fma(-t, b, a) here,
+// fma(t, a, b) there) is materialised by the compiler as TWO scalar register pairs, +t and -t, so that the two-operand form of the
+// FMA (which has no negation modifier) can be used — 15 constants became 60 scalar registers and the kernel, at its limit of 102,
+// spilled scalars and was rescheduled for the worse (round 5: 53 ms against 43; round 6: the same until this).  A value the compiler
+// cannot see through is negated by the instruction's own source modifier.
+struct Tan32 { double t[9], c[9]; };      // t[j] = tan(j pi/32), c[j] = cos(j pi/32), j = 0 .. 8
+__device__ __forceinline__ Tan32 load_tan32()
+{
+    Tan32 k;
+    k.t[0] = 0.0; k.c[0] = 1.0; k.t[8] = 1.0;
+    static_for<1, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; k.t[j] = opaque_scalar(tan_pi32(j)); k.c[j] = opaque_scalar(cos_pi32(j)); });
+    k.c[8] = opaque_scalar(cos_pi32(8));
+    return k;
+}
+// (a - i b) e^{-i K pi/32} / cos(scale32_index(K) pi/32)
+template <int K>
+__device__ __forceinline__ cplx twist32_tan(double a, double b, const Tan32 &k)
+{
+    constexpr Oct32 o = oct32(K);
+    constexpr int Ja = o.J < 0 ? -o.J : o.J;
+    const double t = k.t[Ja];
+    double wr, wi;      // (a - i b)(1 - i ts), ts = +-t:  (a - ts b) - i (b + ts a)
+    if (Ja == 0) { wr = a; wi = -b; }
+    else if (Ja == 8) { if (o.J > 0) { wr = a - b; wi = -(b + a); } else { wr = a + b; wi = a - b; } }
+    else if (o.J > 0) { wr = fma_(-t, b, a); wi = -fma_(t, a, b); }
+    else { wr = fma_(t, b, a); wi = fma_(t, a, -b); }
+    return o.q == 0 ? mk(wr, wi) : o.q == 1 ? mk(wi, -wr) : o.q == 2 ? mk(-wr, -wi) : mk(-wi, wr);      // times (-i)^q
+}
+// dft8<false> of x[r] = s[r] w[r] (s[0] = 1): the scales ride on the first butterfly — r = 0: one FMA per component instead of an
+// addition; r = 1 .. 3: a multiplication, then the FMA.  58 operations (dft8: 52) for 8 points whose twists cost 14 instead of 28.
+template <typename S>
+__device__ __forceinline__ void dft8_fwd_scaled_in(cplx (&x)[8], S s, double r2 /* sqrt(1/2) */)
+{
+    cplx a[4], t[4];
+    static_for<0, 4>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const cplx v = R == 0 ? x[0] : mk(x[R].x * s(rc), x[R].y * s(rc));
+        const double s4 = s(std::integral_constant<int, R + 4>{});
+        a[R] = axpy(v, s4, x[R + 4]);
+        t[R] = axpy(v, -s4, x[R + 4]);
+    });
+    const cplx b1 = mk(t[1].x + t[1].y, t[1].y - t[1].x);     // t1 * (1 - i)   (lacks 1/sqrt(2))
+    const cplx b2 = mk(t[2].y, -t[2].x);                      // t2 * (-i)
+    const cplx b3 = mk(t[3].y - t[3].x, -(t[3].x + t[3].y));  // t3 * (-1 - i) (lacks 1/sqrt(2))
+    {
+        const cplx c0 = cadd(a[0], a[2]), c1 = cadd(a[1], a[3]), d0 = csub(a[0], a[2]), e = csub(a[1], a[3]);
+        const cplx d1 = mk(e.y, -e.x);
+        x[0] = cadd(c0, c1); x[4] = csub(c0, c1); x[2] = cadd(d0, d1); x[6] = csub(d0, d1);
+    }
+    {
+        const cplx c0 = cadd(t[0], b2), d0 = csub(t[0], b2), c1 = cadd(b1, b3), e = csub(b1, b3);
+        const cplx d1 = mk(e.y, -e.x);
+        x[1] = axpy(c0, r2, c1); x[5] = axpy(c0, -r2, c1); x[3] = axpy(d0, r2, d1); x[7] = axpy(d0, -r2, d1);
+    }
+}
+
 // forward 512-point transform of this wave's half (after the radix-2 split), x in / spectrum out
 __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx (&tw1f)[8], const cplx *tw2_lds, cplx *xch)
 {
@@ -1651,12 +1820,38 @@ __device__ __forceinline__ void fft_fwd_half(int lane, cplx (&x)[8], const cplx 
 
 // Recombination of the two inverse half-transforms of one N = 2048 output polynomial (alpha: even frequencies' half, beta:
 // odd), untwist, round, add into the polynomial image `ap` (mirror included): the inverse of the radix-2 split above.
-template <bool MARGIN>
-__device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap, double &worst)
+template <bool MARGIN, bool TAN = false>
+__device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap, double &worst, const Tan32 &k)
 {
     static_for<0, 8>([&](auto rc) {
         constexpr int R = decltype(rc)::value;
         const cplx al = alpha[R], be = beta[R];
+        if constexpr (TAN) {
+            // the same arithmetic with every twist in tan form (twist32_tan): conj(beta) e_r = sB B', p / m = conj(alpha) +- sB B' (the
+            // cosine rides on these additions), p c_r = s0 z0, m c_{r+8} = s1 z1 (the cosines ride on the FMAs that add the rounding constant)
+            const cplx Bp = twist32_tan<4 * R>(be.x, be.y, k);
+            constexpr int iB = scale32_index(4 * R), i0 = scale32_index(R), i1 = scale32_index(R + 8);
+            const double sB = k.c[iB], s0 = k.c[i0], s1 = k.c[i1];
+            const double pr = iB == 0 ? al.x + Bp.x : fma_(sB, Bp.x, al.x), pi = iB == 0 ? Bp.y - al.y : fma_(sB, Bp.y, -al.y);
+            const double mr = iB == 0 ? al.x - Bp.x : fma_(-sB, Bp.x, al.x), mi = iB == 0 ? -al.y - Bp.y : fma_(-sB, Bp.y, -al.y);
+            const cplx z0 = twist32_tan<R>(pr, -pi, k), z1 = twist32_tan<R + 8>(mr, -mi, k);
+            if (MARGIN) {
+                const double f0 = frac_dist(z0.x * s0), f1 = frac_dist(z0.y * s0), f2 = frac_dist(z1.x * s1), f3 = frac_dist(z1.y * s1);
+                worst = f0 > worst ? f0 : worst;
+                worst = f1 > worst ? f1 : worst;
+                worst = f2 > worst ? f2 : worst;
+                worst = f3 > worst ? f3 : worst;
+            }
+            const int jlo = kMir + lane + 64 * R;
+            auto rnd = [](double z, double sc, bool unit) { return (uint32_t)(unit ? round_to_torus32(z) : round_scaled_to_torus32(z, sc)); };
+            ap[jlo] = (int32_t)((uint32_t)ap[jlo] + rnd(z0.x, s0, i0 == 0));
+            ap[jlo + 1024] = (int32_t)((uint32_t)ap[jlo + 1024] + rnd(z0.y, s0, i0 == 0));
+            ap[jlo + 512] = (int32_t)((uint32_t)ap[jlo + 512] + rnd(z1.x, s1, i1 == 0));
+            const int32_t last = (int32_t)((uint32_t)ap[jlo + 1536] + rnd(z1.y, s1, i1 == 0));
+            ap[jlo + 1536] = last;
+            if (R == 7) ap[lane] = (int32_t)(0u - (uint32_t)last);      // coefficient N - 64 + lane: the mirror (rotate_sub3)
+            return;
+        }
         const double er = cos_pi32(4 * R), ei = -sin_pi32(4 * R);               // e_r = e^{-i pi r/8}
         // conj(beta) e_r   (r = 0 and r = 4 written out: without fast-math the products by 0 and 1 are not folded)
         const double br = R == 0 ? be.x : R == 4 ? -be.y : be.x * er + be.y * ei;
@@ -1684,6 +1879,12 @@ __device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], co
     });
 }
 
+template <bool MARGIN>
+__device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap, double &worst)
+{
+    finish_2048<MARGIN, false>(lane, alpha, beta, ap, worst, Tan32{});
+}
+
 // ---- N = 2048: the blind-rotation kernel (round 4; round 3's blind_rotate_kernel_n2048 is in the history) ------------------
 // Two waves per rotation, each computing one half of the frequencies of every transform (above).  Each half needs every
 // coefficient of a rotated polynomial, and until round 3 BOTH waves rotated and offset all 32 coefficient classes of both
@@ -1706,6 +1907,9 @@ template <int L, bool MARGIN = false, int RW = 2>
 __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048Args P)
 {
     constexpr int K1 = 2;
+    // Every constant twist in tan form (round 6; twist32_tan): 92 FP64 instructions less per wave and step, 1 - 1.4 % of the launch.  (Kept
+    // as a switch for the general kernel's sake, which shares finish_2048; the round-2 form of the forward twist is fwd_in_2048.)
+    constexpr bool TAN = true, TANF = true;
     // The first KPN values of the co = 0 key chunk are requested inside the transform, between the store and the load of its
     // second transposition (x[] is dead there; a chunk requested before the transform spills into the loop: 71.7 ms), the
     // rest after the transform: the L2 round trip then overlaps the last radix-8 pass.  Round 3, one device, 4096 rotations of
@@ -1751,6 +1955,8 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 
     int a_next = load_uniform_i32(bara) & (2 * kN2 - 1);
     wave_priority_begin(P.prio_steps);
+    Tan32 tk;
+    if constexpr (TAN || TANF) tk = load_tan32();
     // One copy of the step loop per wave half, chosen ONCE by a scalar branch: the per-half constants of the radix-2 split (the
     // twist angles, the sign of kappa, which block is handed over) are then compile-time constants.  Round 3 selected them per
     // lane (v_cndmask on every constant: faster than scalar branches around every use, 44.6 vs 46.5 ms); with the whole loop
@@ -1789,12 +1995,19 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
                     constexpr int R = decltype(rc)::value;
                     const int32_t lo = digit2(temp[R], p + 1, beta), l2 = digit2(temp[R + 8], p + 1, beta);
                     const int32_t hi = digit2(temp[R + 16], p + 1, beta), h2 = digit2(temp[R + 24], p + 1, beta);
-                    x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
+                    if constexpr (TAN) {
+                        // (u +- kappa u') e^{-i theta_R} / cos: theta_R = R pi/32 (wave 0) or 5 R pi/32 (wave 1) — twist32_tan; the cosine rides on the first butterfly
+                        const double re = fma_(sg, (double)(l2 - h2), (double)lo), im = fma_(sg, (double)(l2 + h2), (double)hi);
+                        x[R] = twist32_tan<(wave1 ? 5 : 1) * R>(re, im, tk);
+                    } else {
+                        x[R] = fwd_in_2048<R>((double)lo, (double)hi, (double)(l2 - h2), (double)(l2 + h2), sg, wave1);
+                    }
                 });
                 STAMP(1);
                 const cplx *kp = key + (size_t)(p * K1 + c) * K1 * 2 * kM + lane;
                 cplx kv0[8];
-                fft_fwd_wave_mid(lane, x, tw1f, tw2_lds, xch, [&]() {
+                if constexpr (TAN) dft8_fwd_scaled_in(x, [&](auto rc) { return tk.c[scale32_index((wave1 ? 5 : 1) * decltype(rc)::value)]; }, tk.c[8]);
+                fft_fwd_wave_mid<false, TAN>(lane, x, tw1f, tw2_lds, xch, [&]() {
 #pragma unroll
                     for (int k2 = 0; k2 < KPN; k2++) kv0[k2] = kp[k2 * 64];
                 });
@@ -1848,7 +2061,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #pragma unroll
         for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
         STAMP(7);
-        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) { finish_2048<MARGIN>(lane, alpha, beta, ap, worst); };
+        auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) { finish_2048<MARGIN, TANF>(lane, alpha, beta, ap, worst, tk); };
         if (wave1) finish(oth, out[1], acc_own);
         else finish(out[0], oth, acc_own);
         WAVE_LDS_FENCE();       // (no barrier: only this wave reads or writes acc_own, and the buffer just read is this wave's again)
