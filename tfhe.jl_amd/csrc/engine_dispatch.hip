@@ -254,7 +254,8 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         // every transform split over two waves: acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256]
         H2Tables ht;
         ht.tw1h = c->d_tables + kH2TableOffset; ht.tw2q = ht.tw1h + 512; ht.tw3q = ht.tw2q + 64;
-        const size_t ldsh = 2 * kImg * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx);
+        // acc[2][N] | transposition buffers [4L][320] | extra slots [4L][256] | rotated differences [2 (step parity)][2][N]
+        const size_t ldsh = 2 * kImg * 4 + (size_t)4 * L * (kH2Buf + 256) * sizeof(cplx) + 2 * 2 * kN * 4;
 #define LAUNCH_H2_(LL, DG)                                                                                         \
         do {                                                                                                       \
             LDS_TRY(c, ldsh, blind_rotate_kernel_h2<LL, DG>); \

@@ -1281,8 +1281,13 @@ __device__ __forceinline__ void fft256_inv(int lane, cplx (&x)[4], const H2LaneT
 // rounded and added to the coefficients read at rotate time (cur), written back with the mirror block (rotate_sub3).
 // H is a template argument: with the half a run-time value both twists were computed and one selected — 8 FP64 operations and
 // 8 selects per point instead of 4 and none (1.710 -> 1.613 ms per single gate).
-template <int H, bool MARGIN>
-__device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], const cplx (&o)[4], const int32_t (&cur)[16], int32_t *acc_lds, double &worst)
+// SC (round 6): instead of writing the updated coefficients to the accumulator image, the owner keeps them in registers (cur8:
+// classes R8 and R8 + 8, R8 = R + 4 H) and ADDS each one twice into the buffer the NEXT step's rotation will be read from —
+// once negated at its own position, once with the rotation's sign at position + a_next: t_next = (X^a' - 1) acc + offset arrives as
+// 16 plain reads per wave instead of 32 reads and the rotation arithmetic in each of the 4 l waves (blind_rotate_kernel_h2).
+template <int H, bool MARGIN, bool SC = false>
+__device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], const cplx (&o)[4], const int32_t (&cur)[16], int32_t *acc_lds, double &worst,
+                                             int32_t (*cur8)[4] = nullptr, uint32_t *t_next = nullptr, int a_next = 0)
 {
     const double rs = 0.70710678118654752440;
     static_for<0, 4>([&](auto rc) {
@@ -1307,6 +1312,20 @@ __device__ __forceinline__ void h2_recombine(int lane, const cplx (&own)[4], con
             worst = fb > worst ? fb : worst;
         }
         const int jlo = lane + 64 * R8;
+        if constexpr (SC) {
+            const int32_t nlo = (int32_t)((uint32_t)cur8[0][R] + (uint32_t)round_scaled_to_torus32(zr, twk(R8)));
+            const int32_t nhi = (int32_t)((uint32_t)cur8[1][R] + (uint32_t)round_scaled_to_torus32(zi, -twk(R8)));
+            cur8[0][R] = nlo; cur8[1][R] = nhi;
+            auto scatter = [&](int j, uint32_t v) {
+                atomicAdd(t_next + j, 0u - v);                                   // - acc[j]
+                const int idx = j + a_next;                                      // X^a' acc: position j + a' (mod 2N), sign by bit 10
+                const uint32_t m = 0u - (((uint32_t)idx >> 10) & 1u);
+                atomicAdd(t_next + (idx & (kN - 1)), (v ^ m) - m);
+            };
+            scatter(jlo, (uint32_t)nlo);
+            scatter(jlo + kM, (uint32_t)nhi);
+            return;
+        }
         const int32_t clo = cur[R8], chi = cur[R8 + 8];     // read at rotate time; nobody else writes them
         const int32_t nlo = (int32_t)((uint32_t)clo + (uint32_t)round_scaled_to_torus32(zr, twk(R8)));
         const int32_t nhi = (int32_t)((uint32_t)chi + (uint32_t)round_scaled_to_torus32(zi, -twk(R8)));
@@ -1331,6 +1350,15 @@ template <int L, bool MARGIN = false>
 __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H2Tables HT)
 {
     constexpr int K1 = 2, W = 2 * K1 * L;
+    // Round 6: the rotation is SCATTERED by the owners instead of gathered by every wave.  All 4 l waves of a rotation need
+    // t = (X^a - 1) acc + offset of their polynomial, whole: until round 5 each of them read the accumulator image twice (its own
+    // coefficients and the rotated ones: 32 LDS reads and the rotation arithmetic per wave and step, behind the barrier that
+    // follows the owners' write).  Now the owner of a coefficient adds it twice — negated at its position, with the rotation's sign
+    // at position + a_next (the next exponent is known a step ahead) — into a buffer that the idle waves of digit 1 have reset to
+    // `offset`, with LDS atomics (the two owners of a polynomial hit arbitrary positions), and every wave starts the next step with 16
+    // plain reads.  The accumulator itself stays in the owners' registers until the extraction.  Same device, interleaved
+    // (profiles/r06/r06l_h2_sc.jsonl): a single gate 1.614 -> 1.537 ms, 16 / 64 / 256 rotations 1.64 / 1.64 / 1.66 -> 1.60 / 1.60 / 1.61.
+    constexpr bool SC = true;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
@@ -1338,6 +1366,7 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     int32_t *acc_all = reinterpret_cast<int32_t *>(smem);                        // [K1][kImg]
     cplx *tb_all = reinterpret_cast<cplx *>(smem + K1 * kImg * 4);               // [W][kH2Buf]
     cplx *extra_all = tb_all + W * kH2Buf;                                       // [W][256]
+    uint32_t *tbuf_all = reinterpret_cast<uint32_t *>(extra_all + W * 256);      // SC: [2 (step parity)][K1][kN] rotated differences + offset
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = wave_in_block();                                              // wave = (p, c, h): owners (p = 0) are waves 0..3, one per SIMD
     const int h = wv & 1, c = (wv >> 1) & 1, p = wv >> 2;
@@ -1371,6 +1400,21 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) { kown[q4] = key_own[q4 * 128]; koth[q4] = key_oth[q4 * 128]; }
     int a_next = load_uniform_i32(bara) & (2 * kN - 1);
+    int32_t cur8[2][4];                           // SC, owners: the coefficients they update (classes R + 4 h and R + 4 h + 8), kept across the steps
+    if constexpr (SC) {
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { cur8[0][r] = acc_lds[kMir + lane + 64 * (r + 4 * h)]; cur8[1][r] = acc_lds[kMir + lane + 64 * (r + 4 * h) + kM]; }
+        }
+        if (p == 0 && h == 0) {                   // step 0's rotated difference, once, by the rotation the other variant runs every step
+            int32_t c0[16], t0[16];
+            load_cur<16>(lane, acc_lds, c0);
+            rotate_sub3<16>(lane, __builtin_amdgcn_readfirstlane(a_next), acc_lds, c0, P.g.offset, 0, t0);
+#pragma unroll
+            for (int m = 0; m < 16; m++) tbuf_all[c * kN + lane + 64 * m] = (uint32_t)t0[m];
+        }
+        __syncthreads();
+    }
     STAMP_DECL;
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
@@ -1378,10 +1422,17 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         cplx x[4];
         int32_t cur[16];                          // this lane's coefficients of polynomial c (an owner adds its half back at the end)
+        uint32_t *t_cur = tbuf_all + ((i & 1) * K1 + c) * kN, *t_next = tbuf_all + (((i + 1) & 1) * K1 + c) * kN;
         {
             int32_t temp[16];
-            load_cur<16>(lane, acc_lds, cur);
-            rotate_sub3<16>(lane, __builtin_amdgcn_readfirstlane(a), acc_lds, cur, P.g.offset, xormask, temp);
+            if constexpr (SC) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) temp[m] = (int32_t)(t_cur[lane + 64 * m] ^ (uint32_t)xormask);
+                (void)a;
+            } else {
+                load_cur<16>(lane, acc_lds, cur);
+                rotate_sub3<16>(lane, __builtin_amdgcn_readfirstlane(a), acc_lds, cur, P.g.offset, xormask, temp);
+            }
             STAMP(0);
             // z_r = (d[t+64r] - i d[t+64r+512]) e^{-i pi r/16} = c_r u_r, r < 8 (tan form: load_digits2t); the half's input is
             // z_r + z_{r+4} (h = 0) or (z_r - z_{r+4}) kappa^r, kappa = e^{-i pi/4} (h = 1) = c_r (u_r +- (c_{r+4} / c_r) u_{r+4}) [kappa^r]:
@@ -1420,6 +1471,15 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         STAMP(3);
         __syncthreads();
         STAMP(4);
+        if constexpr (SC) {
+            // the waves of digit 1 idle through the inverse phase: they reset the buffer the owners are about to add into (half h of
+            // polynomial c each: 512 words, two 16-byte stores per lane) — ordered before those additions by the next barrier
+            if (p == 1) {
+                const uint4 init = make_uint4((uint32_t)P.g.offset, (uint32_t)P.g.offset, (uint32_t)P.g.offset, (uint32_t)P.g.offset);
+                uint4 *q = reinterpret_cast<uint4 *>(t_next + h * (kN / 2));
+                q[lane] = init; q[lane + 64] = init;
+            }
+        }
         if (owner) {
 #pragma unroll
             for (int ow = h; ow < W; ow += 2) {          // the waves of the same half
@@ -1443,14 +1503,21 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = ps[r * 64 + lane];
             // (one copy of the recombination per half, chosen by a scalar branch: h2_recombine)
-            if (h) h2_recombine<1, MARGIN>(lane, own, o, cur, acc_lds, worst);
-            else h2_recombine<0, MARGIN>(lane, own, o, cur, acc_lds, worst);
+            if (h) h2_recombine<1, MARGIN, SC>(lane, own, o, cur, acc_lds, worst, cur8, t_next, a_next);
+            else h2_recombine<0, MARGIN, SC>(lane, own, o, cur, acc_lds, worst, cur8, t_next, a_next);
         }
         STAMP(8);
         __syncthreads();     // the updated polynomials are visible to every wave's rotation
         STAMP(9);
     }
     if (wv < 4) STAMP_FLUSH(P.diag, wv);
+    if constexpr (SC) {                           // the accumulator as the extraction below reads it
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc_lds[kMir + lane + 64 * (r + 4 * h)] = cur8[0][r]; acc_lds[kMir + lane + 64 * (r + 4 * h) + kM] = cur8[1][r]; }
+        }
+        __syncthreads();
+    }
     diag_end<MARGIN>(P.diag, w, worst, dg_t0, dg_r0);
     int32_t *ext = P.ext + w * (kN + 1);
     if (wv == 0) extract_mask_poly(lane, acc_all, ext);
