@@ -354,14 +354,33 @@ int32_t tfhe_last_rounding_margin(tfhe_ctx *ctx, double *worst);
  * one: price rooflines with the reading of a launch that lasts milliseconds. */
 int32_t tfhe_last_kernel_clock_mhz(tfhe_ctx *ctx, double *mhz);
 
-/* Selects a kernel variant / diagnostic by name ("ks_variant", "br_small", "br_tiny", "br_split", "br_general", "br_prio_pct",
- * "measure_margin", "mk_general", "mkg_acc", "ks_slices", "level_split_min", ...: the full list is in tfhe_set_option,
- * csrc/engine_diag.hip; none of them changes a result word).  "ks_variant" decides which keyswitch-key layout is kept on
- * the device and must be chosen before the keyswitch key is loaded (TFHE_ERR_STATE otherwise).
- * "br_rt_l" = 1 runs l = 2 / 3 on the run-time-l instantiations as well (they are otherwise used for every other l; a
- * comparison switch).  "timing_events" (default 1): 0 makes the gate entry points record no per-phase timing events — each record keeps the stream's
- * next kernel waiting ~5 us, which a level of a narrow circuit (six short operations around one single-rotation kernel) feels;
- * tfhe_last_timing_ms / tfhe_timing_history_ms then have nothing to report for those calls (TFHE_ERR_STATE). */
+/* Options by name.  NONE of them changes a result word: they choose among kernels that compute the same thing (the tests
+ * force every kernel through them and compare with the oracle), switch diagnostics on, or move a dispatch threshold.  Defaults
+ * are what the measurements of DESIGN.md chose; thresholds given per compute unit scale with the device (256 CUs on an MI355X).
+ *
+ *   what runs                  "measure_margin" 0|1       the DIAG instantiation of the chosen kernel: rounding margin + in-kernel clock
+ *                              "timing_events"  1|0       0: no per-phase HIP events (each costs the stream ~5 us; tfhe_last_timing_ms then reports nothing)
+ *   host-buffer pipeline       "pipeline_min"   n         tfhe_gates_batch from n gates up runs as two halves on two streams (default 16 per CU; < 0 never)
+ *   multi-device context       "level_split_min" n        levels of at least n rotations are sharded over the devices (default 16 per CU; < 0 never)
+ *                              "level_exchange" 0|1|2     rows between devices: by peer access | device to device | pinned host staging
+ *   kernel by batch size       "br_tiny"  n               up to n rotations: 4 l waves per rotation (h2); default one per CU, -1 never
+ *    (N = 1024, k = 1)         "br_small" n               up to n rotations: two waves per rotation (w2); default 4 per CU, -1 never
+ *                              "br_split" 1|0             a batch above what the chip holds sends its last partly filled round to the two-wave kernel
+ *                              "w2_rw" 0|1|2, "v3_rw" 0|1|4   rotations per workgroup in lockstep (0: by batch size)
+ *                              "br_prio_pct" 0..100       a wave lowers its issue priority over this share of its steps (default 90)
+ *                              "br_rt_l" 0|1              l = 2 / 3 on the run-time-l instantiations too (a comparison switch)
+ *   other shapes               "k2_w3" -1|0|1, "k2_rw" 0|1|7       k = 2: three waves per rotation (by size | never | always), lockstep groups
+ *                              "n2048_rw" 0|1|2           N = 2048: rotations per workgroup
+ *                              "n512_w2" -1|0|1, "n512_rw" 0|1|4   N = 512
+ *                              "br_general" 0|1           every single-key rotation on blind_rotate_kernel_general (cross-check)
+ *                              "br_anyn" 0|1, "anyn_spec" -1|0|1   the any-N kernel where a tuned one exists (decides a KEY LAYOUT: choose before
+ *                                                         loading the bootstrapping key, TFHE_ERR_STATE otherwise); its spectrum accumulators in LDS / global memory
+ *   multi-key                  "mk_rw" 0|1|2, "mk_general" 0|1, "mkg_variant" 0|1, "mkg_rw" 0|1|2|4, "mkg_acc" -1|0|1
+ *   keyswitch                  "ks_variant" 4|3|1         int8 MFMA | tiled integer | gather (decides a KEY LAYOUT: before loading the keyswitch key)
+ *                              "ks_slices" 1|2|4          K-split of the MFMA kernel for large batches
+ *   read-only (tfhe_get_option) "exact_domain", "exact_bound_log2_x1000", "exact_margin_x1e6" (below), "peer_pairs" (multi-device context:
+ *                              ordered pairs of different device contexts that copy device to device)
+ *   tests                      "debug_fail_alloc_after" n (ctx may be NULL; process-wide): see tfhe_get_option */
 int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
 /* Read-only names of tfhe_get_option (ABI v7), decided by tfhe_ctx_create from the parameter set alone — is it inside what a
  * Float64 transform computes exactly ("Exactness domain" above)?
