@@ -393,8 +393,8 @@ int32_t tfhe_set_option(tfhe_ctx *ctx, const char *name, int64_t value);
  *                                 the reference does too and warns (polynomials.jl:135-144) — but a word may differ from the exact
  *                                 product; tfhe_last_rounding_margin measures.  The Python and Julia constructors warn once.
  *   "exact_bound_log2_x1000"  1000 x log2 of that worst-case magnitude
- *   "exact_margin_x1e6"       10^6 x the predicted margin = 4 x 2^-53 x rms x log2(N/2), rms = sqrt(np N) 2^(beta+32) / 12; every
- *                             measured margin of rounds 2-5 lies between 0.35 and 0.9 of it
+ *   "exact_margin_x1e6"       10^6 x the predicted margin = 4.5 x 2^-53 x rms x max(log2(N/2), 4), rms = sqrt(np N) 2^(beta+32) / 12; every
+ *                             measured margin of rounds 2-6 lies between 0.31 and 0.90 of it
  * "debug_fail_alloc_after" (set / get, ctx may be NULL, process-wide, default 0 = off): the n-th allocation checkpoint inside the
  * library from now on throws std::bad_alloc — how the tests show that TFHE_ERR_NOMEM comes back and the context survives. */
 /* The current value of an option (ABI v6): a caller that changes one for a while can put it back.  "br_anyn" (the any-N kernel

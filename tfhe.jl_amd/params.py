@@ -33,7 +33,7 @@ class SchemeParameters:
         N, beta = self.tlwe_polynomial_degree, self.bs_log2_base
         bound_log2 = math.log2(products * N) + (beta - 1) + 31
         rms = math.sqrt(products * N) * 2.0 ** (beta + 32) / 12.0
-        margin = 4.0 * 2.0 ** -53 * rms * max(1.0, math.log2(N / 2))
+        margin = 4.5 * 2.0 ** -53 * rms * max(4.0, math.log2(N / 2))
         ok = margin < 0.25 and 8.0 * rms < 2.0 ** 51
         return (0 if not ok else 2 if bound_log2 < 51.0 else 1), bound_log2, margin
 
