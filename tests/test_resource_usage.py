@@ -79,3 +79,47 @@ def test_blind_rotate_kernels_keep_two_waves_per_simd():
     assert len(anyn) == 7 and all(rep[k]["scratch"] == 0 for k in anyn), anyn
     rt = [k for k in rep if re.search(r"void blind_rotate_kernel_(v3|w2)<0,", k)]
     assert len(rt) == 7 and all((rep[k]["scratch"] == 0 or k in DIAG_MAY_SPILL) and rep[k]["occ"] >= 2 for k in rt), rt
+
+
+def _disassemble(obj):
+    """gfx950 disassembly of one translation unit of the shipped library: {mangled kernel name: [instruction lines]}."""
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               f"--input={fat}", f"--output={co}"])
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
+    kernels, cur = {}, None
+    for line in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.strip():
+            cur.append(line)
+    return kernels
+
+
+def test_kernels_at_the_scalar_register_limit_keep_their_schedule():
+    """Round 6: a Float64 constant used with both signs is materialised as two scalar register pairs; in the N = 2048 and
+    2-party multi-key kernels, which sit at the 102-SGPR limit, that meant scalar spills (v_readlane / v_writelane) and a fallback
+    schedule that drains the LDS queue (`s_waitcnt lgkmcnt(0)`) 70 - 131 times where the kernel has 39 — bit-identical and 16 - 23 %
+    slower, twice.  The constants are opaque now; this reads the shipped code objects so that the schedule cannot flip unnoticed."""
+    _report()                                   # (builds the library if it is stale)
+    build = os.path.join(ROOT, "tfhe.jl_amd", "build")
+    disp = _disassemble(os.path.join(build, "engine_dispatch.o"))
+    mk = _disassemble(os.path.join(build, "engine_multikey.o"))
+
+    def stats(body):
+        return {"drains": sum("lgkmcnt(0)" in l for l in body), "readlane": sum("v_readlane" in l for l in body),
+                "scratch": sum("scratch_" in l for l in body), "insts": len(body)}
+    n2048 = {k: stats(v) for k, v in disp.items() if "blind_rotate_kernel_n2048x" in k}
+    assert len(n2048) == 3, list(n2048)
+    for k, st in n2048.items():
+        diag = "ELb1E" in k                     # (the DIAG instantiation carries two more 64-bit stamps and a live double: two scalar reloads, outside the transform loops)
+        assert st["readlane"] <= (4 if diag else 0) and st["scratch"] == 0 and st["drains"] <= 50, (k, st)        # 39 drains in the two-rotation instantiation
+    mkw2 = {k: stats(v) for k, v in mk.items() if "mk_blind_rotate_kernel_w2" in k and "ELb0E" in k}
+    assert len(mkw2) == 2, list(mkw2)
+    for k, st in mkw2.items():
+        assert st["readlane"] == 0 and st["scratch"] <= 8 and st["drains"] <= 140, (k, st)       # 119 drains; three spilled dwords = 4 - 6 scratch instructions
