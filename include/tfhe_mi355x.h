@@ -247,8 +247,9 @@ int32_t tfhe_gates_batch(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *i
  * (every other one). */
 int32_t tfhe_gates_batch_submit(tfhe_ctx *ctx, const uint8_t *opcodes, const int32_t *in0, const int32_t *in1,
                                 const int32_t *in2, int32_t *out, int64_t B, int32_t *ticket);
-/* wait: callable from any thread (ABI v7).  From a thread other than the one inside a call on ctx it waits for everything queued
- * on ctx (tfhe_ctx_synchronize) instead of failing with TFHE_ERR_STATE. */
+/* wait: callable from any thread (ABI v7).  From the thread that submitted, it waits for the ticket and releases its slot.  From any
+ * other thread it never takes the context — it cannot make the submitting thread's calls fail — and waits for everything queued
+ * on ctx (tfhe_ctx_synchronize); the slot is released by the submitting thread's next submit or wait. */
 int32_t tfhe_gates_batch_wait(tfhe_ctx *ctx, int32_t ticket);
 
 /* Same with DEVICE pointers for in0/in1/in2/out (opcodes stay a host array) on HIP stream `stream`

@@ -199,6 +199,7 @@ struct tfhe_ctx {
     std::atomic<hipStream_t> twin_stream{nullptr};      // the twin's stream, published once by ensure_twin: tfhe_ctx_synchronize reads it from any thread
     bool borrows_keys = false;
     bool slot_busy[2] = {false, false};   // tfhe_gates_batch_submit: a batch is in flight on the own (0) / the twin's (1) stream
+    std::atomic<std::thread::id> submit_thread{};      // the thread of the last tfhe_gates_batch_submit: ITS waits release the slot, any other thread's wait only waits
     uint32_t submits = 0;
     // multi-device context: coherence of the replicated wire table.  wire_valid[k][w]: device k's replica holds wire w's
     // current value; wire_owner[w]: a device that does (the one that wrote it last).  A level's outputs become valid on the

@@ -409,6 +409,7 @@ int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32
         }
         c->submits++;
         c->slot_busy[slot] = true;
+        c->submit_thread.store(std::this_thread::get_id(), std::memory_order_release);
         *ticket = slot;
         return TFHE_OK;
     }
@@ -436,20 +437,28 @@ int32_t tfhe_gates_batch_submit(tfhe_ctx *c, const uint8_t *opcodes, const int32
     if (slot) { c->last_rotations = t->last_rotations; c->last_kernel = t->last_kernel; }     // tfhe_last_rotation_count / _kernel_name describe the newest submit, whichever stream took it
     c->submits++;
     c->slot_busy[slot] = true;
+    c->submit_thread.store(std::this_thread::get_id(), std::memory_order_release);
     *ticket = slot;
     return TFHE_OK;
 }
 ABI_CATCH(c, "tfhe_gates_batch_submit")
 
-// Callable from any thread, also while another thread is inside a call on the context (ABI v7): the owner of the context waits for
-// the ticket's stream and clears the slot; anybody else gets the unguarded wait of tfhe_ctx_synchronize — everything queued so
-// far, a superset of the ticket's batch — and the slot stays marked until the owner's next submit or wait finds the stream idle.
-// (Until v6 a wait that overlapped another thread's call returned TFHE_ERR_STATE at once, and a caller that then freed the
-// batch's page-locked buffers — a finalizer — freed them under a live DMA.)
+// Callable from any thread, also while another thread is inside a call on the context (ABI v7).  From the thread that submitted:
+// the wait for the ticket's stream, and the slot is released.  From ANY OTHER thread — a finalizer, a task that migrated — it
+// never takes the context (so it cannot make the submitting thread's next call fail with TFHE_ERR_STATE either): it gets the
+// unguarded wait of tfhe_ctx_synchronize — everything queued so far, a superset of the ticket's batch — and the slot stays
+// marked until the submitting thread's next submit or wait finds the stream idle.  (Until v6 a wait that overlapped another
+// thread's call returned TFHE_ERR_STATE at once, and a caller that then freed the batch's page-locked buffers — a finalizer —
+// freed them under a live DMA.)
 int32_t tfhe_gates_batch_wait(tfhe_ctx *c, int32_t ticket) try
 {
     if (!c) return TFHE_ERR_INVALID_ARG;
     alloc_checkpoint();
+    const std::thread::id submitter = c->submit_thread.load(std::memory_order_acquire);
+    if (submitter != std::thread::id{} && submitter != std::this_thread::get_id() && c->owner.load(std::memory_order_acquire) != std::this_thread::get_id()) {
+        if (ticket != 0 && ticket != 1 && ticket != 2) return TFHE_ERR_INVALID_ARG;
+        return ticket == 2 ? TFHE_OK : tfhe_ctx_synchronize(c);
+    }
     CallGuard call_guard_(c);
     if (!call_guard_.ok) {
         if (g_rejected_ctx == c) g_rejected_ctx = nullptr;      // (not an error here)
