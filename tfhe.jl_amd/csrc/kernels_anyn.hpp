@@ -3,7 +3,7 @@
 //
 // SchemeParameters is an unvalidated positional struct (api.jl:4-21) and the reference's transform works for any even length
 // (polynomials.jl:44-58,106-132): a parameter set it accepts must not be refused here because no tuned kernel was written
-// for it.  The tuned kernels (kernels_blind_rotate.hpp) are built around N = 1024 / 2048 as 8 complex points per lane of a
+// for it.  The tuned kernels (kernels_blind_rotate.hpp and the family headers it lists) are built around N = 1024 / 2048 as 8 complex points per lane of a
 // 64-lane wave; this file makes no such assumption.  One workgroup per rotation, nothing sized by a template parameter:
 //   * the folded M = N/2-point transform (polynomials.jl:106-112) is an in-place mixed-radix decimation-in-frequency FFT in
 //     LDS — radix-8 stages while 8 divides what is left, then one radix-4 or radix-2 stage — and leaves the spectrum in
@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 #include "br_core.hpp"
-#include "kernels_blind_rotate.hpp"
+#include "kernels_common.hpp"
 
 using namespace tfhe;
 
@@ -396,7 +396,7 @@ __global__ void bk_permute_c128_kernel(const cplx *__restrict__ in, cplx *__rest
     out[e] = mk(v.x * s, v.y * s);
 }
 
-// ---- RGSW.Expand (mk_internals.jl:304-345) for any N: the counterpart of mk_expand_kernel (kernels_blind_rotate.hpp) ----------
+// ---- RGSW.Expand (mk_internals.jl:304-345) for any N: the counterpart of mk_expand_kernel (kernels_keyprep.hpp) ----------
 //     x[jj, q] = d0[jj] + sum_u g^-1(b_q[jj] - b_i[jj])[u] (*) f0[u]          y[jj, q] = sum_u g^-1(...)[u] (*) f1[u]
 // One workgroup per output polynomial: l spectrum products, one inverse transform, one rounding.
 #endif  // TFHE_EMIT_KEYPREP_KERNELS

@@ -5,7 +5,7 @@
 // transforms; this kernel is blind_rotate_kernel_v3's design at half the size: one 64-lane wave owns one accumulator for all n
 // CMUX steps, a polynomial of 512 coefficients is M = 256 folded complex points, FOUR per lane (lane t holds points t + 64 r,
 // r < 4, i.e. coefficients t + 64 m, m < 8), and the 256-point transform is the four-radix-4-pass, three-transposition transform
-// blind_rotate_kernel_h2 already uses for its half-transforms (fft256_fwd / fft256_inv, kernels_blind_rotate.hpp) with the lane
+// blind_rotate_kernel_h2 already uses for its half-transforms (fft256_fwd / fft256_inv, kernels_h2.hpp) with the lane
 // part of THIS degree's twist folded into its first twiddles.  With 16 registers of transform state instead of 32 the wave fits
 // three to a SIMD (152 registers, no scratch); 9.7 KB of LDS per rotation.  (Measured and not kept: FOUR waves per SIMD — 119
 // registers with the later passes' twiddles in a 1.3 KB LDS table per workgroup, four workgroups of four rotations exactly filling a
@@ -18,7 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "br_core.hpp"
-#include "kernels_blind_rotate.hpp"
+#include "kernels_h2.hpp"      // the 256-point transforms (fft256_fwd / fft256_inv)
 
 using namespace tfhe;
 

@@ -3,7 +3,7 @@
 // build time, now in parallel with one another and with the engine).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "kernels_blind_rotate.hpp"
+#include "kernels_multikey.hpp"
 
 #define TFHE_G2_LAUNCHER(P, L, DG, RW, AL) tfhe_launch_mk_g2_##P##_##L##_##DG##_##RW##_##AL
 #define TFHE_G2_DECLARE(P, L, DG, RW, AL) hipError_t TFHE_G2_LAUNCHER(P, L, DG, RW, AL)(unsigned nblk, size_t lds_bytes, hipStream_t s, const MkGenArgs &ga)
