@@ -178,7 +178,7 @@ static int32_t launch_blind_rotate_part(tfhe_ctx *c, size_t first, size_t R, int
         b.diag = a.diag; b.bara = a.bara; b.bk = a.bk; b.ext = a.ext; b.tw1f2 = c->d_tables + kTableElems; b.tw2 = c->T.tw2; b.g = c->g; b.n = a.n; b.mu = mu; b.prio_steps = a.prio_steps;
         b.R = (int32_t)R;
         const int rw = dg ? 1 : c->n2048_rw ? c->n2048_rw : (R <= (size_t)c->cu_count ? 1 : 2);     // (the DIAG instantiation exists for single rotations only)
-        const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx);
+        const size_t ldsb = (size_t)rw * (2 * kImg2 * 4 + 2 * kXchElems * sizeof(cplx)) + 64 * sizeof(cplx) + 64;      // (+ the hand-off words of the pairs)
         const unsigned nblk = (unsigned)((R + rw - 1) / rw);
 #define LAUNCH_2048(DG, RWV)                                                                                       \
         do {                                                                                                       \

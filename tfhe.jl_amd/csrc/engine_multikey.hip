@@ -92,7 +92,7 @@ int32_t tfhe_mk_gate_nand_batch(tfhe_ctx *c, const int32_t *in0, const int32_t *
         // two waves per rotation: acc[3][N] | xch[2] | second hand-off slot [M] | tw2   (39.4 KB: four workgroups per CU)
         // mk_rw rotations per workgroup in lockstep (2: default: 78.8 KB, two workgroups per CU; 1: 39.4 KB, four; DIAG: 1)
         const int rw = dg ? 1 : c->mk_rw ? c->mk_rw : ((size_t)B <= (size_t)c->cu_count ? 1 : 2);
-        const size_t lds2 = (size_t)rw * ((NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx);
+        const size_t lds2 = (size_t)rw * ((NP + 1) * kImg * 4 + (2 * kXchElems + kM) * sizeof(cplx)) + 64 * sizeof(cplx) + 64;      // (+ the hand-off words of the pairs)
         const unsigned nblk = (unsigned)((B + rw - 1) / rw);
         a.R = (int32_t)B;
 #define LAUNCH_MK2(LL, DG, RWV)                                                                                    \

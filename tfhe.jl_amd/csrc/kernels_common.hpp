@@ -336,3 +336,44 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
     for (int q = 0; q < 8; q++) x[q] = cmulc(x[q], tw1f[q]);
     dft8<true>(x);
 }
+
+// ---- hand-offs between the two waves of a rotation without a workgroup barrier (round 6: blind_rotate_kernel_n2048x, mk_blind_rotate_kernel_w2) ----
+// A workgroup-wide barrier at every hand-off makes each rotation of a workgroup wait for the slowest one twice per step; the hand-off itself
+// concerns two waves.
+// Each wave of the pair owns one LDS word; it stores the number of the hand-off it has just written (after the data: a wave's LDS
+// operations execute in order) and polls the partner's word until it shows the same number.  Both waves of a pair run the same
+// number of steps and a wave signals hand-off k before it waits for k, so neither can wait for a signal that never comes; the poll is
+// bounded all the same (a wave that gives up leaves wrong words, which every parity test sees, instead of a hung device).
+__device__ __forceinline__ void pair_signal(int *flag_own, int k)
+{
+    WAVE_LDS_FENCE();
+    *reinterpret_cast<volatile int *>(flag_own) = k;
+}
+// `take()` reads the partner's block.  The word is requested FIRST and the block behind it in the same batch: the LDS serves a wave's
+// requests in order, so a block read behind a word that already showed k is the block the partner wrote before it — when the partner
+// is there already (the usual case: the two waves do the same work) the hand-off costs one LDS round trip, not two.
+template <typename TAKE>
+__device__ __forceinline__ void pair_wait_take(const int *flag_other, int k, TAKE &&take)
+{
+    const int f0 = *reinterpret_cast<const volatile int *>(flag_other);
+    WAVE_LDS_FENCE();
+    take();
+    WAVE_LDS_FENCE();
+    if (__builtin_amdgcn_readfirstlane(f0) - k >= 0) return;
+    // the partner is behind: poll the word alone (a block re-read per poll would take the LDS from the waves that are working), then read
+    for (int spin = 0; spin < (1 << 24); spin++) {
+        __builtin_amdgcn_s_sleep(1);
+        const int f = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(flag_other));
+        if (f - k >= 0) break;
+    }
+    WAVE_LDS_FENCE();
+    take();
+    WAVE_LDS_FENCE();
+}
+__device__ __forceinline__ void pair_wait(const int *flag_other, int k)
+{
+    pair_wait_take(flag_other, k, []() {});
+}
+// CMUX steps between the workgroup barriers that keep the rotations of a workgroup within reach of one another's key fetches (they share
+// the key's trips through the L1): 8 / 16 / 32 / 64 / 128 / never measured on config 4b: 42.7 / 42.4 / 42.3 – 42.9 / 42.8 / 42.9 / 43.1 ms
+constexpr int kPairSyncEvery = 32;

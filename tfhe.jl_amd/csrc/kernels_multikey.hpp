@@ -30,12 +30,12 @@ struct MkBrArgs {
 // digits of the other mask; wave 1: every digit of the body and the other half) and multiply them into their own
 // partial sums of the three new polynomials (mk_internals.jl:371-385); the partial sums are handed over through LDS (wave 1 gives the two mask partials to
 // wave 0, wave 0 the body partial to wave 1), each owner adds what it receives, inverse-transforms and updates its
-// polynomials.  Two barriers per step (hand-off written / accumulator updated).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
+// polynomials.  Two synchronisations of the pair per step (hand-off written / accumulator updated: pair_signal, kernels_common.hpp).  All 1024 rotations are resident at two waves per SIMD (39.4 KB of LDS per workgroup: the hand-off
 // reuses the transposition buffers).  Same words as the any-party kernel (round 3's one-wave 2-party kernel is gone).  L must be even.
-template <int L, int PARTY, int WV, bool MARGIN, int TAN>
+template <int L, int PARTY, int WV, bool MARGIN, int TAN, bool PAIR>
 __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, const int32_t *bara, int32_t *acc_lds,
                                                 cplx *xch_own, cplx *xch_oth, cplx *extra, const cplx *tw2_lds, const cplx (&tw1f)[8],
-                                                int32_t xormask, double &worst, const Tan16 &tk)
+                                                int32_t xormask, double &worst, const Tan16 &tk, int *pair_flags)
 {
     constexpr int NP = 2;
     constexpr int PER = 2 * L * NP + 2 * L;       // key polys per (party, bit): x[L][NP] | y[L][NP] | c0[L] | c1[L]
@@ -47,6 +47,8 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
 #pragma unroll 1
     for (int j = 0; j < P.n; j++) {
         wave_priority_step(PARTY * P.n + j, P.prio_steps);
+        const int g = PARTY * P.n + j;            // step of the rotation: its two hand-offs are numbered 2 g + 1 and 2 g + 2 (pair_signal)
+        if (PAIR && (g & (kPairSyncEvery - 1)) == 0) __syncthreads();
         const int a = a_next;
         a_next = load_uniform_i32(bara + PARTY * P.n + j + 1) & (2 * kN - 1);      // the row ends with barb: the read past the last bit is in range
         // (the lane is made opaque once per step: per-lane addresses — the 64-bit key pointer, the LDS transposition and
@@ -127,14 +129,26 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
             for (int k2 = 0; k2 < 8; k2++) { xch_own[k2 * 64 + lane] = out[0][k2]; extra[k2 * 64 + lane] = out[1][k2]; }
         }
         STAMP(3);
-        __syncthreads();
-        STAMP(4);
-        if (WV == 0) {
+        {
+            constexpr int NG = WV == 0 ? 2 : 1;       // wave 0 receives the two mask partials, wave 1 the body partial
+            cplx got[NG][8];
+            auto take = [&]() {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) { out[0][k2] = cadd(out[0][k2], xch_oth[k2 * 64 + lane]); out[1][k2] = cadd(out[1][k2], extra[k2 * 64 + lane]); }
-        } else {
+                for (int k2 = 0; k2 < 8; k2++) {
+                    got[0][k2] = xch_oth[k2 * 64 + lane];
+                    if (WV == 0) got[NG - 1][k2] = extra[k2 * 64 + lane];
+                }
+            };
+            if (PAIR) { pair_signal(pair_flags + WV, 2 * g + 1); pair_wait_take(pair_flags + (1 - WV), 2 * g + 1, take); }
+            else { __syncthreads(); take(); }
+            STAMP(4);
+            if (WV == 0) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cadd(out[NP][k2], xch_oth[k2 * 64 + lane]);
+                for (int k2 = 0; k2 < 8; k2++) { out[0][k2] = cadd(out[0][k2], got[0][k2]); out[1][k2] = cadd(out[1][k2], got[NG - 1][k2]); }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; k2++) out[NP][k2] = cadd(out[NP][k2], got[0][k2]);
+            }
         }
         STAMP(5);
         // No barrier here: the inverse transforms run in the OTHER wave's transposition buffer, the one this wave has just
@@ -156,7 +170,8 @@ __device__ __forceinline__ void mk2_party_steps(int lane_in, const MkBrArgs &P, 
         if (WV == 0) { finish(out[0], 0); finish(out[1], 1); }
         else finish(out[NP], NP);
         STAMP(7);
-        __syncthreads();      // the updated accumulator is visible to both waves' rotations of the next step
+        // the updated accumulator is visible to both waves' rotations of the next step, and the buffer this wave transformed in is its owner's again
+        if (PAIR) { pair_signal(pair_flags + WV, 2 * g + 2); pair_wait(pair_flags + (1 - WV), 2 * g + 2); } else __syncthreads();
         STAMP(8);
     }
     if (PARTY == 1) STAMP_FLUSH(P.diag, WV);
@@ -183,6 +198,8 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + (NP + 1) * kImg * 4);   // [2 waves][kXchElems]
     cplx *extra = xch_all + 2 * kXchElems;                                       // [512] second hand-off slot of wave 1
     cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);             // [8][8]
+    int *pair_flags = reinterpret_cast<int *>(smem + RW * kRotBytes + 64 * sizeof(cplx)) + rot * 2;      // [RW][2]: pair_signal
+    constexpr bool PAIR = RW > 1;      // (one rotation per workgroup: the pair is the workgroup, barriers)
     cplx *xch_own = xch_all + wv * kXchElems, *xch_oth = xch_all + (1 - wv) * kXchElems;
     const size_t w_raw = (size_t)blockIdx.x * RW + rot;
     const bool live = w_raw < (size_t)P.R;                                       // a padding rotation repeats the last one, stores nothing
@@ -194,6 +211,7 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.T.tw1f[q * 64 + lane];
     if (wib == 0) tw2_lds[lane] = P.T.tw2[lane];
+    if (lane == 0) pair_flags[wv] = 0;
     // acc = (0, ..., 0, X^{-barb} * mu)       mk_internals.jl:491-492, 72-79
     if (wv == 0) { init_zero_poly(lane, acc_lds); init_zero_poly(lane, acc_lds + kImg); }
     else init_body_poly(lane, bara[NP * P.n] & (2 * kN - 1), P.mu, acc_lds + 2 * kImg);
@@ -203,11 +221,11 @@ __global__ __launch_bounds__(128 * RW, 2) void mk_blind_rotate_kernel_w2(MkBrArg
     if constexpr (TAN != 0) tk = load_tan16<(TAN == 2)>();
     // party-major double loop (mk_internals.jl:475-476)
     if (wv == 0) {
-        mk2_party_steps<L, 0, 0, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
-        mk2_party_steps<L, 1, 0, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
+        mk2_party_steps<L, 0, 0, MARGIN, TAN, PAIR>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk, pair_flags);
+        mk2_party_steps<L, 1, 0, MARGIN, TAN, PAIR>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk, pair_flags);
     } else {
-        mk2_party_steps<L, 0, 1, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
-        mk2_party_steps<L, 1, 1, MARGIN, TAN>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk);
+        mk2_party_steps<L, 0, 1, MARGIN, TAN, PAIR>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk, pair_flags);
+        mk2_party_steps<L, 1, 1, MARGIN, TAN, PAIR>(lane, P, bara, acc_lds, xch_own, xch_oth, extra, tw2_lds, tw1f, xormask, worst, tk, pair_flags);
     }
     if (!live) return;
     const int lane_e = lane_id_fresh();

@@ -7,7 +7,7 @@
 //   a_j = z_j + z_{j+512}  -> wave 0 -> even frequencies,   b_j = (z_j - z_{j+512}) W_1024^j -> wave 1 -> odd,
 // then each wave runs the same 512-point transform as the N = 1024 kernels on its half, MACs its own
 // frequencies and inverse-transforms them; then wave 0 recombines output polynomial 0 and wave 1 polynomial 1 (one
-// 8 KB hand-off each way, two barriers per step).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
+// 8 KB hand-off each way, two synchronisations of the pair per step).  With z_j = u_j w^j, w = e^{-i pi/2048}, w^512 = kappa = e^{-i pi/4}, j = t + 64 r:
 //   wave 0 pass-A input  x_r = e^{-i pi r/32}  (u + kappa u'),   lane factor w^t             in tw1f
 //   wave 1 pass-A input  x_r = e^{-i pi 5r/32} (u - kappa u'),   lane factor w^t W_1024^t    in tw1f
 // Every wave decomposes all four coefficient classes it needs (t+64m, m < 32) itself; the rotation of a polynomial is done
@@ -213,7 +213,8 @@ __device__ __forceinline__ void finish_2048(int lane, const cplx (&alpha)[8], co
 // Then both inverse half-transforms; wave 0 recombines output polynomial 0 and wave 1 polynomial 1 (finish_2048), so each
 // hands ONE 8 KB block over, and that hand-off swaps the buffers back.  A wave's LDS operations execute in order, so a
 // buffer a wave has just read is free for it to write; the buffer it gave away it does not touch until the next exchange.
-// Two barriers per step, one rotation per wave, 16 16-byte LDS operations for the exchange.
+// Two hand-offs per step (a barrier when the workgroup is one rotation, a polled word per wave otherwise: pair_signal), one rotation per
+// wave, 16 16-byte LDS operations for the exchange.
 // RW rotations per workgroup advance in lockstep (the barriers are workgroup-wide): the transformed key of N = 2048 sets
 // (124 MB at n = 630, l = 3) does not stay in the 4 MB L2 of an XCD once workgroups drift apart, and rotations that read the
 // same key values at the same time share one trip to the Infinity Cache (one / two / four per workgroup: 53.4 / 44.5 / 47.4 ms).
@@ -232,6 +233,14 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
     // rest after the transform: the L2 round trip then overlaps the last radix-8 pass.  Round 3, one device, 4096 rotations of
     // config 4b: 0: 54.2 ms, 1: 49.8, 2: 48.0, 3: 49.9, 4: 49.3-50.1, 6: 48.6-49.2, 8: 49.4-50.4
     constexpr int KPN = 2;
+    // Round 6: with several rotations per workgroup the two hand-offs of a step synchronise only the two waves they concern (pair_signal /
+    // pair_wait_take) instead of the whole workgroup; the rotations meet at a barrier every kPairSyncEvery steps, which is what keeps them
+    // sharing the key's trips through the L1.  Same device, 4096 rotations of config 4b, barrier at every hand-off: 43.2 / 44.1 ms; meeting
+    // every 8 / 16 / 32 / 64 / 128 steps: 42.7 / 42.4 / 42.3 – 42.9 / 42.8 / 42.9; never: 43.1 (the rotations drift apart and each fetches its own
+    // key); the words with a barrier at every step as well: 44.0 — a hand-off through a polled word costs more than a barrier that all four
+    // waves reach together, and less than waiting for the slower rotation twice per step (profiles/r06/r06p_n2048_pair.txt).  One rotation
+    // per workgroup: the pair IS the workgroup, the barrier stays.
+    constexpr bool PAIR = RW > 1;
     unsigned long long dg_t0 = 0, dg_r0 = 0;
     diag_begin<MARGIN>(dg_t0, dg_r0);
     double worst = 0.0;
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
     int32_t *acc_lds = reinterpret_cast<int32_t *>(smem + rot * kRotBytes);       // [K1][kImg2]
     cplx *xch_all = reinterpret_cast<cplx *>(smem + rot * kRotBytes + K1 * kImg2 * 4);   // [2][kXchElems]
     cplx *tw2_lds = reinterpret_cast<cplx *>(smem + RW * kRotBytes);              // [8][8]
+    int *pair_flags = reinterpret_cast<int *>(smem + RW * kRotBytes + 64 * sizeof(cplx)) + rot * 2;      // [RW][2]: see pair_signal
     const bool wave1_0 = ((tid >> 6) & 1) != 0;
     const int wv = wib & 1;                         // scalar copy: buffer and accumulator bases stay in scalar registers
     int32_t *acc_own = acc_lds + wv * kImg2;                                       // wave c owns polynomial c
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #pragma unroll
     for (int q = 0; q < 8; q++) tw1f[q] = P.tw1f2[(wave1_0 ? 512 : 0) + q * 64 + lane0];
     if (tid < 64) tw2_lds[tid] = P.tw2[tid];
+    if (lane0 == 0) pair_flags[wib & 1] = 0;
     {
         const int barb = bara[P.n] & (2 * kN2 - 1);
         int32_t v[32];
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
         wave_priority_step(i, P.prio_steps);
+        if (PAIR && RW > 1 && (i & (kPairSyncEvery - 1)) == 0) __syncthreads();      // the rotations of a workgroup stay within kPairSyncEvery steps of one another (they share the key's trips through the L1)
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN2 - 1);
         // (the lane rebuilt per step: what is derived from it is recomputed here instead of living, and being spilled, across
@@ -348,13 +360,15 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
                 int4 *mine = reinterpret_cast<int4 *>(xch);
 #pragma unroll
                 for (int j = 0; j < 8; j++) mine[j * 64 + lane] = make_int4(temp[4 * j], temp[4 * j + 1], temp[4 * j + 2], temp[4 * j + 3]);
-                __syncthreads();
                 const int4 *theirs = reinterpret_cast<const int4 *>(xch_other);
+                auto take = [&]() {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int4 v = theirs[j * 64 + lane];
-                    temp[4 * j] = v.x; temp[4 * j + 1] = v.y; temp[4 * j + 2] = v.z; temp[4 * j + 3] = v.w;
-                }
+                    for (int j = 0; j < 8; j++) {
+                        const int4 v = theirs[j * 64 + lane];
+                        temp[4 * j] = v.x; temp[4 * j + 1] = v.y; temp[4 * j + 2] = v.z; temp[4 * j + 3] = v.w;
+                    }
+                };
+                if (PAIR) { pair_signal(pair_flags + wv, 2 * i + 1); pair_wait_take(pair_flags + (1 - wv), 2 * i + 1, take); } else { __syncthreads(); take(); }
                 WAVE_LDS_FENCE();
                 cplx *t = xch; xch = xch_other; xch_other = t;
                 STAMP(10);
@@ -372,11 +386,12 @@ __global__ __launch_bounds__(128 * RW, 2) void blind_rotate_kernel_n2048x(Br2048
 #pragma unroll
             for (int r = 0; r < 8; r++) xch[r * 64 + lane] = out[1][r];
         }
-        __syncthreads();
-        STAMP(6);
         cplx oth[8];
+        auto take2 = [&]() {
 #pragma unroll
-        for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+            for (int r = 0; r < 8; r++) oth[r] = xch_other[r * 64 + lane];
+        };
+        if (PAIR) { pair_signal(pair_flags + wv, 2 * i + 2); pair_wait_take(pair_flags + (1 - wv), 2 * i + 2, take2); } else { __syncthreads(); STAMP(6); take2(); }
         STAMP(7);
         auto finish = [&](const cplx (&alpha)[8], const cplx (&beta)[8], int32_t *ap) { finish_2048<MARGIN, TANF>(lane, alpha, beta, ap, worst, tk); };
         if (wave1) finish(oth, out[1], acc_own);
