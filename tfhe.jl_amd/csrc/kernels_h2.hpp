@@ -252,6 +252,12 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
     STAMP_DECL;
 #pragma unroll 1
     for (int i = 0; i < P.n; i++) {
+        // Issue priority through the forward phase, where every SIMD holds an owner and the L - 1 waves of the other digits: the
+        // hardware favours the oldest wave — the owner —, which then waits at the barrier below for the others to finish alone at a lone
+        // wave's rate.  The other digits' waves go first up to the end of their transform, the owner through its products and hand-off
+        // (round 6, same device: single gate 1.558 -> 1.516 ms, 256 gates 1.619 -> 1.518, tfhe_parameters_128 2.377 -> 2.247 and
+        // 2.406 -> 2.242; raised later in the step or held longer it LOSES 2 - 5 %: profiles/r06/r06q_h2_prio.txt)
+        if (p != 0) __builtin_amdgcn_s_setprio(1);
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         cplx x[4];
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         }
         STAMP(1);
         fft256_fwd<true>(lane, x, tw, tb, Dft4Scale{kTwG0, kTwR1, h ? kTwSL : kTwL});      // s1 = c1 / sqrt(2) : c1
+        if (p != 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
         STAMP(2);
         cplx own[4], oth[4];                     // this wave's contribution to output component c / 1 - c (half h)
 #pragma unroll
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) tb[q4 * 64 + lane] = own[q4];
         }
+        if (p == 0) __builtin_amdgcn_s_setprio(0);
         STAMP(3);
         __syncthreads();
         STAMP(4);
