@@ -229,6 +229,32 @@ def test_n2048_kernel(tfhe, orc):
     K.ck.close()
 
 
+def test_pair_handoffs_across_the_meeting_barrier(tfhe, orc):
+    """Round 6: with two rotations per workgroup the hand-offs of blind_rotate_kernel_n2048x and mk_blind_rotate_kernel_w2 synchronise the two
+    waves they concern through polled LDS words (pair_signal, kernels_common.hpp) and the rotations meet at a workgroup barrier every 32
+    steps.  The small cases of this file have 8 - 12 steps: here 70 (N = 2048) and 2 x 40 (two parties) — across the meeting barrier twice —,
+    an odd number of rotations (the last workgroup holds a padding rotation, which must keep every appointment of its pair and of its
+    workgroup) and two rotations per workgroup forced on a batch the dispatcher would run one by one."""
+    K = _setup(tfhe, orc, 2048, 1, 3, BETA_OTHER[3], n=70, seed=6)
+    eng = K.ck.engine(0)
+    x = _words(np.random.default_rng(406), 7, K.params.lwe_size + 1)
+    eng.set_option("n2048_rw", 2)
+    got = eng.bootstrap(MU, x, with_keyswitch=False)
+    assert eng.last_kernel_name() == "blind_rotate_kernel_n2048x<3,rw2>"
+    assert np.array_equal(got, K.oracle.bootstrap(MU, x, with_keyswitch=False, nthreads=8))
+    K.ck.close()
+    p, rng, sks, ck, o = _mk(tfhe, orc, 2, 4, 7, 40, 2, 606)
+    eng = ck.engine(0)
+    x, y = _words(rng, 7, 2 * 40 + 1), _words(rng, 7, 2 * 40 + 1)[::-1].copy()
+    x[2:4] = tfhe.mk_encrypt(rng, sks, [True, False])
+    y[2:4] = tfhe.mk_encrypt(rng, sks, [True, True])
+    eng.set_option("mk_rw", 2)
+    got = eng.mk_gate_nand(x, y)
+    assert eng.last_kernel_name() == "mk_blind_rotate_kernel_w2<4>"
+    assert np.array_equal(got, o.mk_gate_nand(x, y, nthreads=8))
+    ck.close()
+
+
 GENERAL = [  # what, N, k, l, beta        parameter sets the reference accepts (api.jl:4-21,30,55) and no specialised kernel covers
     ("tfhe_parameters_80(tlwe_mask_size=3)", 1024, 3, 2, 10),
     ("tlwe_mask_size=4", 1024, 4, 2, 8),
