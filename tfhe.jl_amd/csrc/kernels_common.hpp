@@ -343,7 +343,10 @@ __device__ __forceinline__ void fft_inv_wave(int lane, cplx (&x)[8], const cplx 
 // Each wave of the pair owns one LDS word; it stores the number of the hand-off it has just written (after the data: a wave's LDS
 // operations execute in order) and polls the partner's word until it shows the same number.  Both waves of a pair run the same
 // number of steps and a wave signals hand-off k before it waits for k, so neither can wait for a signal that never comes; the poll is
-// bounded all the same (a wave that gives up leaves wrong words, which every parity test sees, instead of a hung device).
+// bounded all the same: kPairGiveUp polls of ~170 cycles each are ~2.5 ms, a hundred steps of the slowest kernel, where a partner that
+// is merely behind arrives within a fraction of one step; a wave that gives up leaves wrong words, which every parity test sees, and a
+// launch in which every wait gave up would still end after seconds, not hang the device.
+constexpr int kPairGiveUp = 1 << 15;
 __device__ __forceinline__ void pair_signal(int *flag_own, int k)
 {
     WAVE_LDS_FENCE();
@@ -361,7 +364,7 @@ __device__ __forceinline__ void pair_wait_take(const int *flag_other, int k, TAK
     WAVE_LDS_FENCE();
     if (__builtin_amdgcn_readfirstlane(f0) - k >= 0) return;
     // the partner is behind: poll the word alone (a block re-read per poll would take the LDS from the waves that are working), then read
-    for (int spin = 0; spin < (1 << 24); spin++) {
+    for (int spin = 0; spin < kPairGiveUp; spin++) {
         __builtin_amdgcn_s_sleep(1);
         const int f = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(flag_other));
         if (f - k >= 0) break;
