@@ -361,7 +361,7 @@ def main():
         fanout_ok = bool(np.array_equal(ref, out[lo:]))
 
     # --- extras on rank 0, outside the timed region ---------------------------------------------------
-    single_ms = pcie_value = pcie_sync = pcie_pageable = clock_mhz = margin = None
+    single_ms = single_ms_noev = pcie_value = pcie_sync = pcie_pageable = clock_mhz = margin = None
     if rank == 0 and not args.fanout:
         if args.workload == "nand":   # "ms/bootstrap" half of the metric: latency of ONE gate_nand (B = 1)
             one = np.zeros(1, np.uint8)
@@ -375,6 +375,21 @@ def main():
                 lat.append(time.perf_counter() - t1)
             single_ms = float(np.median(lat[5:])) * 1e3
             assert torch.equal(o1[0], dout[0]), "single-gate result differs from the batched one"
+            # the same with the engine's per-phase timing events off (option "timing_events" = 0, what circuit.py runs its levels with:
+            # each of the four event records of a call costs the stream ~5 us between two kernels); reported beside, never instead
+            eng.set_option("timing_events", 0)
+            try:
+                lat = []
+                for it in range(25):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    eng.gates_dev(one, dx.data_ptr(), dy.data_ptr(), dz.data_ptr(), o1.data_ptr(), 1, stream)
+                    torch.cuda.synchronize(dev)
+                    lat.append(time.perf_counter() - t1)
+                single_ms_noev = float(np.median(lat[5:])) * 1e3
+                assert torch.equal(o1[0], dout[0]), "single-gate result differs from the batched one"
+            finally:
+                eng.set_option("timing_events", 1)
         if not args.no_diagnostics and world == 1:
             # the same step through HOST buffers (tfhe_gates_batch: 2-3 uploads + 1 download over PCIe per step)
             reps = max(2, min(args.steps, 5))
@@ -448,6 +463,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_bootstrap_amortised": elapsed / args.steps * 1e3 / B,
             "ms_per_bootstrap_single_gate": single_ms,
+            "ms_per_bootstrap_single_gate_without_timing_events": single_ms_noev,
             "higher_is_better": True,
             "scaling": "weak" if args.workload == "nand" else "strong",
             "vs_baseline": None,
