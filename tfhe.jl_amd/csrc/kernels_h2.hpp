@@ -257,7 +257,9 @@ __global__ __launch_bounds__(256 * L, 1) void blind_rotate_kernel_h2(BrArgs P, H
         // wave's rate.  The other digits' waves go first up to the end of their transform, the owner through its products and hand-off
         // (round 6, same device: single gate 1.558 -> 1.516 ms, 256 gates 1.619 -> 1.518, tfhe_parameters_128 2.377 -> 2.247 and
         // 2.406 -> 2.242; raised later in the step or held longer it LOSES 2 - 5 %: profiles/r06/r06q_h2_prio.txt)
-        if (p != 0) __builtin_amdgcn_s_setprio(1);
+        // (l = 3: the third digit's waves one level above the second's — neutral there; written as two tests because THIS form compiles to the
+        //  register allocation that measures 0.7 % (one gate) to 1.6 % (64 gates) faster than `p != 0` at l = 2, on two devices: r06q, block 4)
+        if (p == 1) __builtin_amdgcn_s_setprio(1); else if (p == 2) __builtin_amdgcn_s_setprio(2);
         const int a = a_next;
         a_next = load_uniform_i32(bara + i + 1) & (2 * kN - 1);   // bara[n] (= barb) exists: harmless read on the last step
         cplx x[4];
